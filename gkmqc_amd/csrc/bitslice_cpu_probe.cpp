@@ -1,0 +1,63 @@
+/*
+ * bitslice_cpu_probe.cpp -- runs the per-lane bit-sliced program of gkm_bitslice.h on
+ * the CPU for one (row sequence, column sequence) pair.  UNIT-TEST HARNESS for the
+ * product's kernel logic (tests/test_bitslice_core.py); it is not linked into
+ * gkmkern_pylib.so and is not a fallback path.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "gkm_bitslice.h"
+
+using namespace gkmbs;
+
+template <int W, int L, int D>
+static void run_pair(const uint8_t *A, int lenA, const uint8_t *wtA, const uint8_t *B, int lenB,
+                     const uint8_t *wtB, uint32_t *acc /* [1<<NB] */)
+{
+    constexpr int NB = planes_for(D);
+    constexpr int CAP = segment_capacity(W, L);
+    const int nA = lenA - L + 1, nB = lenB - L + 1, T = lenB;
+    for (int k = 0; k < (1 << NB); k++) acc[k] = 0;
+    std::vector<uint32_t> sb[2][3];
+    for (int st = 0; st < 2; st++)
+        for (int pl = 0; pl < 3; pl++) {
+            sb[st][pl].resize((size_t)T + W);
+            for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
+        }
+    for (int s0 = 0; s0 < nA; s0 += CAP) {
+        uint32_t Ahi[W], Alo[W], AV[W];
+        for (int w = 0; w < W; w++) {
+            Ahi[w] = row_plane_word(A, lenA, s0, w, W, L, 0);
+            Alo[w] = row_plane_word(A, lenA, s0, w, W, L, 1);
+            AV[w] = row_plane_word(A, lenA, s0, w, W, L, 2);
+        }
+        for (int st = 0; st < 2; st++)
+            for (int delta = 0; delta < T; delta++) {
+                Count<NB> cnt[W];
+                window_counts<W, L, NB>(Ahi, Alo, &sb[st][0][(size_t)delta], &sb[st][1][(size_t)delta], cnt);
+                for (int w = 0; w < W; w++) {
+                    const uint32_t h = count_le<NB, D>(cnt[w]) & AV[w] & sb[st][2][(size_t)delta + w];
+                    consume_hits<W, NB>(h, cnt[w].b, delta, w, st, s0, T, nB, wtA ? wtA : nullptr,
+                                        wtA ? wtB : nullptr, acc);
+                }
+            }
+    }
+}
+
+#define CASE(WW, LL, DD) \
+    if (W == WW && L == LL && d == DD) { run_pair<WW, LL, DD>(A, lenA, wtA, B, lenB, wtB, acc); ok = 1; }
+
+extern "C" int bsprobe_profile(int W, int L, int d, const uint8_t *A, int lenA, const uint8_t *wtA,
+                               const uint8_t *B, int lenB, const uint8_t *wtB, int32_t *P)
+{
+    uint32_t acc[16] = {0};
+    int ok = 0;
+    CASE(10, 11, 3) CASE(10, 10, 3) CASE(10, 12, 4) CASE(10, 8, 4) CASE(10, 9, 4) CASE(10, 12, 6)
+    CASE(10, 4, 2) CASE(10, 2, 1) CASE(10, 3, 0) CASE(10, 5, 2) CASE(10, 6, 3) CASE(10, 7, 3)
+    CASE(5, 11, 3) CASE(16, 11, 3) CASE(3, 12, 4) CASE(10, 12, 8) CASE(10, 12, 12) CASE(10, 11, 1)
+    if (!ok) return 1;
+    for (int m = 0; m <= d; m++) P[m] = (int32_t)acc[m];
+    return 0;
+}

@@ -1,0 +1,98 @@
+/*
+ * gkm_hip.h -- device-layer C ABI of the gkm kernel-matrix path (MI355X / gfx950).
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  `gkm_main_pywrapper`
+ * (include/gkmkern_pylib.h) is a thin C host on top of these calls; bench.py and
+ * the GPU tests bind them with ctypes and pass device pointers and a HIP stream
+ * obtained from PyTorch-ROCm.
+ *
+ * What each call replaces in the reference (all in src/libgkm.c unless noted):
+ *   gkmhip_create / gkmhip_destroy   gkmkernel_init :978-1033, gkmkernel_destroy :1058-1068
+ *   gkmhip_set_sequences             gkmkernel_new_object :841-938 (encoding, rc strand,
+ *                                    positional weights) + gkmkernel_build_tree :1035-1056
+ *                                    (the k-mer tree is replaced by bit-plane tables)
+ *   gkmhip_gram_rows                 the row loop pthread_gkmkernel_kernelfunc_batch_all
+ *                                    (src/gkmkern_pylib.c:70-90) -> gkmkernel_kernelfunc_batch_all
+ *                                    :1156-1185 -> kmertree_dfs :315-387, for a set of rows;
+ *                                    it also yields the self terms of
+ *                                    gkmkernel_kernelfunc_sqnorm_single :723-759
+ *   gkmhip_normalize                 the division / RBF of :1168-1179 and the unit diagonal
+ *                                    of src/gkmkern_pylib.c:218-221
+ *
+ * Output convention: `G` is a row-major fp64 matrix with leading dimension `ld`
+ * (elements).  gkmhip_gram_rows writes RAW values G(a,j) = sum_m c_m P_m(a,j) for
+ * j <= a (diagonal included, nothing above it).  gkmhip_normalize turns a matrix
+ * of raw values (all rows present) into K in place.
+ *
+ * All functions return 0 on success and a non-zero code on failure;
+ * gkmhip_last_error() describes the most recent failure of the calling thread.
+ */
+#ifndef GKM_HIP_H
+#define GKM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gkmhip_ctx gkmhip_ctx;
+
+enum { GKMHIP_KERNEL_AUTO = 0, GKMHIP_KERNEL_DIRECT = 1, GKMHIP_KERNEL_BITSLICE = 2 };
+
+const char *gkmhip_last_error(void);
+int gkmhip_device_count(void);
+
+/* c: the d+1 mismatch weights c_0..c_d (host-computed, include/gkmkern_pylib.h).
+ * rbf != 0 selects K <- exp(gamma (K-1)) in gkmhip_normalize (kernel types 3, 5). */
+gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, double gamma);
+void gkmhip_destroy(gkmhip_ctx *ctx);
+
+/* choose the kernel family (default AUTO: bit-sliced where supported) */
+int gkmhip_set_kernel(gkmhip_ctx *ctx, int which);
+
+/* Upload n sequences.  codes: base codes 0..3, concatenated; offsets[n+1] (elements).
+ * wt: forward positional weights, concatenated, n_i = len_i - L + 1 per sequence;
+ * wt_offsets[n+1].  weighted == 0 means all weights are 1 (wt may be NULL).
+ * Builds every device table the kernels need (asynchronously on `stream`). */
+int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
+                         const uint8_t *wt, const int64_t *wt_offsets, int weighted, void *stream);
+
+/* Raw Gram values for the rows listed in `rows` (host array of nrows ascending sequence
+ * indices): row rows[i] is written to G + i*ld (local_rows != 0) or to
+ * G + rows[i]*ld (local_rows == 0).  `G` is a DEVICE pointer.  If P != NULL (device,
+ * int32) the integer mismatch profiles are stored as P[(i_or_row*ldp + j)*(d+1) + m]
+ * for j <= a.  Work is enqueued on `stream` (a hipStream_t, may be NULL). */
+int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                     int64_t ld, int32_t *P, int64_t ldp, void *stream);
+
+/* In place on a device matrix holding raw values for ALL n rows (lower triangle +
+ * diagonal): K(a,j) = G(a,j) / (sqrt(G(a,a)) sqrt(G(j,j))), optional RBF, K(a,a)=1.
+ * If sqnorm != NULL (device, n doubles) it receives sqrt(G(a,a)).
+ * symmetric != 0 additionally mirrors the lower triangle into the upper one. */
+int gkmhip_normalize(gkmhip_ctx *ctx, double *G, int64_t ld, double *sqnorm, int symmetric,
+                     void *stream);
+
+/* plain device memory helpers so that a C host needs nothing but this header */
+void *gkmhip_malloc(int device, size_t bytes);
+void gkmhip_free(void *p);
+int gkmhip_memcpy_d2h(void *dst, const void *src, size_t bytes);
+int gkmhip_memcpy_h2d(void *dst, const void *src, size_t bytes);
+int gkmhip_sync(void *stream);
+
+/* Copy the lower triangle (+ diagonal) of a device K (n rows, ld) into caller-owned
+ * host row pointers: rows[a][0..a].  Uses pinned staging and `nthreads` host threads. */
+int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64_t ld, int n,
+                              double **rows, int nthreads);
+
+/* elapsed milliseconds of the device work of the most recent gkmhip_gram_rows call
+ * (HIP events recorded on its stream around the dominant kernel); <0 if unavailable */
+double gkmhip_last_kernel_ms(gkmhip_ctx *ctx);
+/* number of l-mer comparisons that call evaluated (algorithmic: 2 n_a n_j per pair) */
+double gkmhip_last_comparisons(gkmhip_ctx *ctx);
+const char *gkmhip_last_kernel_name(gkmhip_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the COMPILED REFERENCE.
+
+Run in the development container only (needs /root/reference):
+
+    make -C oracle all ref
+    python tests/golden/make_golden.py            # everything except the full C2 run
+    python tests/golden/make_golden.py --c2-full  # + full 10 000 x 10 000 reference run (minutes)
+
+The reference has no tests or known-answer vectors of its own, so
+every expected value here is an OUTPUT OF THE REFERENCE ITSELF:
+  * oracle/_ref/gkmkern_pylib_ref.so  -- unmodified gkm_main_pywrapper  -> K matrices
+  * oracle/_ref/ref_probe.so          -- unmodified libgkm.c internals   -> c_m, positional
+                                         weights, sqnorm, integer mismatch profiles
+Fixtures are data only: FASTA inputs we wrote/generated ourselves + expected outputs.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as O  # noqa: E402
+from gkmqc_amd import synth  # noqa: E402
+
+# (kernel_type, L, k, d, M, H, gamma)
+QUIRK_PARAMS = [
+    (4, 11, 7, 3, 50, 50.0, 1.0),
+    (2, 10, 6, 3, 50, 50.0, 1.0),
+    (4, 12, 8, 4, 50, 50.0, 1.0),
+    (0, 8, 4, 4, 50, 50.0, 1.0),
+    (3, 10, 6, 3, 50, 50.0, 2.0),
+    (5, 11, 7, 3, 50, 50.0, 2.0),
+    (1, 11, 7, 3, 50, 50.0, 1.0),
+    (4, 10, 6, 3, 255, 20.0, 1.0),
+    (2, 4, 2, 2, 50, 50.0, 1.0),
+    (4, 9, 5, 4, 30, 7.0, 1.0),
+    (0, 12, 6, 6, 50, 50.0, 1.0),
+]
+
+WEIGHT_TUPLES = [(t, L, k, d) for t in range(6) for (L, k, d) in
+                 [(10, 6, 3), (11, 7, 3), (12, 8, 4), (8, 4, 4), (6, 3, 3), (12, 6, 6), (2, 1, 1), (9, 9, 0)]]
+
+
+def rc(s):
+    return s[::-1].translate(bytes.maketrans(b"ACGTacgt", b"TGCAtgca"))
+
+
+def write_quirks():
+    """A small FASTA pair exercising the reader's and encoder's corner cases."""
+    rng = np.random.default_rng(20241003)
+
+    def rnd(n):
+        return synth._BASES[rng.integers(0, 4, n)].tobytes()
+
+    pos, neg = [], []
+    lens = [30, 45, 64, 100, 150, 151, 299, 300, 301, 320, 321, 333, 450, 600, 640, 700]
+    for i, ln in enumerate(lens):
+        pos.append((b"p%d" % i, [rnd(ln)]))
+        neg.append((b"n%d some description here" % i, [rnd(lens[-1 - i])]))
+    base = pos[7][1][0]
+    pos.append((b"lower", [base[:120].lower()]))                      # case folding
+    pos.append((b"dup_of_p7", [base]))                                # duplicate sequence
+    pos.append((b"rc_of_p7", [rc(base)]))                             # reverse-complement pair
+    pos.append((b"polyA", [b"A" * 100]))                              # dense hits
+    pos.append((b"polyAC", [b"AC" * 60]))
+    s = bytearray(rnd(200)); s[10] = ord("N"); s[50:54] = b"NNNN"; s[120] = ord("x"); s[199] = ord("-")
+    pos.append((b"withN", [bytes(s)]))                                # non-ACGT -> A
+    w = rnd(305)
+    pos.append((b"wrapped", [w[i:i + 60] for i in range(0, len(w), 60)]))  # multi-line record
+    long = rnd(2500)
+    pos.append((b"toolong", [long[i:i + 500] for i in range(0, 2500, 500)]))  # truncated to 2047
+    neg.append((b"crlf", [rnd(80) + b"\r", rnd(70) + b"\r"]))          # CRLF line ends
+    neg.append((b"exact2047", [rnd(1000), rnd(1000), rnd(47)]))
+    neg.append((b"short_as_L", [rnd(12)]))                             # exactly one 12-mer
+    neg.append((b"mixedcase", [b"acgtACGTacgtNNNNacgtacgtacgtTTTTGGGGCCCCAAAAcgcgcgatatat"]))
+    neg.append((b"tabs\tin header", [rnd(90)]))
+
+    def dump(path, recs, crlf_names=(b"crlf",)):
+        with open(path, "wb") as f:
+            for name, lines in recs:
+                f.write(b">" + name + b"\n")
+                for ln in lines:
+                    f.write(ln + b"\n")
+                f.write(b"\n")
+
+    pp, pn = os.path.join(HERE, "quirks_pos.fa"), os.path.join(HERE, "quirks_neg.fa")
+    dump(pp, pos)
+    dump(pn, neg)
+    return pp, pn
+
+
+def tril_pack(K):
+    i, j = np.tril_indices(K.shape[0], -1)
+    return K[i, j].copy()
+
+
+def ref_K(opt, n):
+    rc_, kmat, npos, nneg = O.ref_pywrapper(opt, n)
+    assert rc_ == 0 and npos + nneg == n
+    return kmat, npos
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c2-full", action="store_true")
+    args = ap.parse_args()
+    if not O.have_ref():
+        raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
+
+    # (i) mismatch weights c_m, bit patterns as hex
+    wt = {}
+    for (t, L, k, d) in WEIGHT_TUPLES:
+        if O.lib().gkmo_check_params(t, L, k, d):
+            continue
+        wt["%d,%d,%d,%d" % (t, L, k, d)] = [float(x).hex() for x in O.ref_weights(t, L, k, d)]
+    json.dump(wt, open(os.path.join(HERE, "mismatch_weights.json"), "w"), indent=0, sort_keys=True)
+
+    # (ii)+(iii) quirks FASTA: lengths, positional weights, sqnorm, int profiles, K
+    pp, pn = write_quirks()
+    out = {}
+    for idx, (t, L, k, d, M, H, g) in enumerate(QUIRK_PARAMS):
+        opt = O.make_opt(t, L, k, d, M, H, g, pp, pn, nthreads=4)
+        r = O.ref_profiles(opt)
+        n = r["n"]
+        K, npos = ref_K(opt, n)
+        tag = "q%d" % idx
+        out[tag + "_params"] = np.array([t, L, k, d, M, H, g], dtype=np.float64)
+        out[tag + "_P"] = r["P"]
+        out[tag + "_sqnorm"] = r["sqnorm"]
+        out[tag + "_K"] = tril_pack(K)
+        out[tag + "_wt"] = r["wt"][:, : int(r["lens"].max())]
+        out["lens"] = r["lens"]
+        out["n_pos"] = np.array(npos)
+        print("quirks", (t, L, k, d, M, H, g), "N", n, "npos", npos)
+    np.savez_compressed(os.path.join(HERE, "quirks_expected.npz"), **out)
+
+    # (iv)/(v) synthetic configs (inputs are regenerated from gkmqc_amd.synth, not stored)
+    tmp = os.path.join(ROOT, "gpurun_out", "golden_tmp")
+    os.makedirs(tmp, exist_ok=True)
+    cfgs = {
+        # name: (n_pos, n_neg, length, length_range, t, L, k, d)
+        "c1_full": (200, 200, 300, None, 2, 10, 6, 3),
+        "c2_cut192": (192, 192, 300, None, 4, 11, 7, 3),
+        "c5_cut64": (64, 64, None, (150, 600), 4, 12, 8, 4),
+    }
+    syn = {}
+    for name, (npos, nneg, ln, lr, t, L, k, d) in cfgs.items():
+        pf, nf = os.path.join(tmp, name + "_p.fa"), os.path.join(tmp, name + "_n.fa")
+        synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
+        opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=8)
+        K, _ = ref_K(opt, npos + nneg)
+        syn[name + "_K"] = tril_pack(K)
+        syn[name + "_cfg"] = np.array([npos, nneg, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0, t, L, k, d])
+        if name != "c1_full":
+            r = O.ref_profiles(opt)
+            syn[name + "_P"] = r["P"]
+            syn[name + "_sqnorm"] = r["sqnorm"]
+        print(name, "done")
+    np.savez_compressed(os.path.join(HERE, "synthetic_expected.npz"), **syn)
+
+    if args.c2_full:
+        # (vi) full C2 through the reference: digest + sampled entries + row sums
+        import time
+        npos = nneg = 5000
+        pf, nf = os.path.join(tmp, "c2_p.fa"), os.path.join(tmp, "c2_n.fa")
+        synth.write_problem(pf, nf, npos, nneg, 300)
+        opt = O.make_opt(4, 11, 7, 3, 50, 50.0, 1.0, pf, nf, nthreads=os.cpu_count())
+        t0 = time.time()
+        K, _ = ref_K(opt, npos + nneg)
+        wall = time.time() - t0
+        tri = tril_pack(K)
+        rng = np.random.default_rng(7)
+        sel = rng.choice(tri.size, 4000, replace=False)
+        np.savez_compressed(os.path.join(HERE, "c2_full_digest.npz"),
+                            sha256=np.frombuffer(hashlib.sha256(tri.tobytes()).digest(), dtype=np.uint8),
+                            sample_idx=sel, sample_val=tri[sel],
+                            row_sums=np.tril(K, -1).sum(axis=1), total=np.array(tri.sum()),
+                            ref_wall_s=np.array(wall), ref_threads=np.array(os.cpu_count()))
+        print("c2 full: reference wall %.1f s on %d threads" % (wall, os.cpu_count()))
+
+
+if __name__ == "__main__":
+    main()
