@@ -1,0 +1,792 @@
+/*
+ * gkm_device.hip -- MI355X (gfx950) device layer of the gkm kernel-matrix path.
+ * Implements include/gkm_hip.h.  Written for CDNA4 only: 64-wide wavefronts, one
+ * wavefront per workgroup in the hot kernels, column tables streamed through the
+ * scalar unit (SGPRs), per-wave hit queues in LDS.
+ *
+ * Kernels
+ *   k_pack_lmers      2-bit packed l-mers of both strands (direct kernel input)
+ *   k_build_sb        column-strand bit-plane tables, strided layout (gkm_bitslice.h)
+ *   k_build_rowplanes row-segment bit planes for one set of rows
+ *   k_gram_bitslice   HOT: bit-sliced diagonal mismatch profile -> raw Gram values
+ *   k_gram_direct     general fallback: l-mer by l-mer XOR/popcount
+ *   k_sqnorm, k_normalize   diagonal square roots, division, RBF, unit diagonal
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/gkm_hip.h"
+#include "gkm_bitslice.h"
+
+#define GKM_MAXD1 13 /* d <= 12 */
+
+/* ------------------------------------------------------------------ errors */
+static thread_local std::string g_err;
+
+static int set_err(const char *what, hipError_t e, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+    return 100 + (int)e;
+}
+static int set_err_msg(const std::string &m, int code)
+{
+    g_err = m;
+    return code;
+}
+#define HIPCHK(expr)                                                        \
+    do {                                                                    \
+        hipError_t e_ = (expr);                                             \
+        if (e_ != hipSuccess) return set_err(#expr, e_, __FILE__, __LINE__); \
+    } while (0)
+
+extern "C" const char *gkmhip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int gkmhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+/* ----------------------------------------------------------------- context */
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t count)
+    {
+        if (count <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        HIPCHK(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
+        cap = count;
+        return 0;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct gkmhip_ctx {
+    int device = 0;
+    int L = 0, d = 0, rbf = 0, kernel_pref = GKMHIP_KERNEL_AUTO;
+    double c[GKM_MAXD1] = {0};
+    double gamma = 1.0;
+    int n = 0, weighted = 0, maxlen = 0;
+    std::vector<int> h_len;
+    std::vector<int64_t> h_lmoff;
+    std::vector<double> h_cum_n; /* prefix sums of n_j = len_j - L + 1 */
+    DevBuf<uint8_t> codes, wt;
+    DevBuf<int64_t> off, lmoff;
+    DevBuf<int> len;
+    DevBuf<uint32_t> lmf, lmr, sb;
+    int sb_xw = 0, sb_W = 0;
+    bool have_lmers = false, have_sb = false;
+    /* per-call scratch */
+    DevBuf<int> rows, seg_seq, seg_s0, seg_slot, tile_amax;
+    DevBuf<uint32_t> rowplanes;
+    DevBuf<double> sq;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    double last_comparisons = 0;
+    const char *last_kernel = "none";
+    /* pinned staging for D2H */
+    double *stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+};
+
+extern "C" gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, double gamma)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device available (hipGetDeviceCount)";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { g_err = "device ordinal out of range"; return nullptr; }
+    if (L < 2 || L > 12 || d < 0 || d > 12 || d > L) { g_err = "unsupported (L, d)"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    gkmhip_ctx *ctx = new gkmhip_ctx();
+    ctx->device = device;
+    ctx->L = L;
+    ctx->d = d;
+    ctx->rbf = rbf;
+    ctx->gamma = gamma;
+    for (int m = 0; m <= d; m++) ctx->c[m] = c[m];
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        g_err = "hipEventCreate failed";
+        delete ctx;
+        return nullptr;
+    }
+    const char *env = getenv("GKM_KERNEL");
+    if (env) {
+        if (!strcmp(env, "direct")) ctx->kernel_pref = GKMHIP_KERNEL_DIRECT;
+        else if (!strcmp(env, "bitslice")) ctx->kernel_pref = GKMHIP_KERNEL_BITSLICE;
+    }
+    return ctx;
+}
+
+extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    ctx->codes.release(); ctx->wt.release(); ctx->off.release(); ctx->lmoff.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
+    ctx->rows.release(); ctx->seg_seq.release(); ctx->seg_s0.release(); ctx->seg_slot.release();
+    ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->sq.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int i = 0; i < 2; i++)
+        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+    delete ctx;
+}
+
+extern "C" int gkmhip_set_kernel(gkmhip_ctx *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 2) return set_err_msg("bad kernel selector", 2);
+    ctx->kernel_pref = which;
+    return 0;
+}
+
+/* ----------------------------------------------------------- prep kernels */
+/* one workgroup per sequence; 2-bit packed l-mers of the forward strand and of the
+ * reverse-complement strand (rc l-mer p = l-mer p of rc(seq), libgkm.c:877-888) */
+__global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
+                             const int64_t *__restrict__ lmoff, int L, uint32_t *__restrict__ lmf,
+                             uint32_t *__restrict__ lmr)
+{
+    const int s = blockIdx.x;
+    const uint8_t *seq = codes + off[s];
+    const int len = (int)(off[s + 1] - off[s]);
+    const int n = len - L + 1;
+    const int64_t o = lmoff[s];
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        uint32_t f = 0, r = 0;
+        for (int i = 0; i < L; i++) {
+            f = (f << 2) | seq[p + i];
+            r = (r << 2) | (3u - seq[len - 1 - (p + i)]);
+        }
+        lmf[o + p] = f;
+        lmr[o + p] = r;
+    }
+}
+
+/* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
+__global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
+                           int L, int xw, uint32_t *__restrict__ sb)
+{
+    const int e = blockIdx.x, plane = blockIdx.y;
+    const int s = e >> 1, strand = e & 1;
+    const uint8_t *seq = codes + off[s];
+    const int T = (int)(off[s + 1] - off[s]);
+    uint32_t *dst = sb + ((size_t)e * 3 + plane) * xw;
+    for (int x = threadIdx.x; x < xw; x += blockDim.x)
+        dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
+}
+
+/* grid (tile, plane); 64 threads = the tile's lanes; layout [tile][plane][w][lane] */
+__global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
+                                  const int *__restrict__ seg_seq, const int *__restrict__ seg_s0, int W,
+                                  int L, uint32_t *__restrict__ planes)
+{
+    const int tile = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
+    const int s = seg_seq[tile * 64 + lane];
+    const int s0 = seg_s0[tile * 64 + lane];
+    for (int w = 0; w < W; w++) {
+        uint32_t v = 0u;
+        if (s >= 0) {
+            const int len = (int)(off[s + 1] - off[s]);
+            v = gkmbs::row_plane_word(codes + off[s], len, s0, w, W, L, plane);
+        }
+        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] = v;
+    }
+}
+
+/* ------------------------------------------------------------ hot kernels */
+struct GramOut {
+    double *G;
+    int64_t ld;
+    int32_t *P;
+    int64_t ldp;
+    int local_rows;
+};
+
+struct BsArgs {
+    const uint32_t *rowplanes;
+    const int *seg_seq, *seg_s0, *seg_slot, *tile_amax;
+    const uint32_t *sb;
+    int xw;
+    const int *len;
+    const int64_t *lmoff;
+    const uint8_t *wt;
+    double c[GKM_MAXD1];
+    GramOut out;
+    int cj, maxseg;
+};
+
+typedef const uint32_t __attribute__((address_space(4))) * sgpr_words;
+
+constexpr int BS_CAP = 16; /* hit-queue entries per lane */
+constexpr int BS_DU = 5;   /* shifts per SB register refill */
+
+/*
+ * One wavefront = 64 row segments (one per lane) x a chunk of `cj` column sequences.
+ * For every column strand the wave sweeps all T cyclic shifts; per shift each lane
+ * evaluates 32*W l-mer window comparisons with ~40 integer ops per 32 (gkm_bitslice.h).
+ * Hit words are parked in a per-lane LDS queue and turned into weighted profile counts
+ * in batches, so the hot loop has no data-dependent control flow besides the push.
+ */
+template <int W, int L, int D, bool WEIGHTED>
+__global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
+{
+    using namespace gkmbs;
+    constexpr int NB = planes_for(D);
+    constexpr int NACC = 1 << NB;
+    constexpr int NF = NB + 2; /* queue fields: h, count planes, meta */
+    __shared__ uint32_t q[NF * BS_CAP * 64];
+
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.y;
+    const int amax = A.tile_amax[tile];
+    const int j0 = blockIdx.x * A.cj;
+    const int j1 = min(j0 + A.cj, amax + 1);
+    if (j0 >= j1) return;
+
+    uint32_t Ahi[W], Alo[W], AV[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        Ahi[w] = A.rowplanes[(((size_t)tile * 3 + 0) * W + w) * 64 + lane];
+        Alo[w] = A.rowplanes[(((size_t)tile * 3 + 1) * W + w) * 64 + lane];
+        AV[w] = A.rowplanes[(((size_t)tile * 3 + 2) * W + w) * 64 + lane];
+    }
+    const int myseq = A.seg_seq[tile * 64 + lane];
+    const int s0 = A.seg_s0[tile * 64 + lane];
+    const int slot = A.seg_slot[tile * 64 + lane];
+    const uint8_t *wtA = WEIGHTED ? (A.wt + (myseq >= 0 ? A.lmoff[myseq] : 0)) : nullptr;
+
+    for (int j = j0; j < j1; j++) {
+        const int T = A.len[j];
+        const int nB = T - L + 1;
+        const uint8_t *wtB = WEIGHTED ? (A.wt + A.lmoff[j]) : nullptr;
+        uint32_t acc[NACC];
+#pragma unroll
+        for (int k = 0; k < NACC; k++) acc[k] = 0u;
+        int qn = 0;
+
+        auto drain = [&]() {
+            for (int e = 0; __any(e < qn); e++) {
+                if (e < qn) {
+                    const uint32_t h = q[(0 * BS_CAP + e) * 64 + lane];
+                    uint32_t cb[NB];
+#pragma unroll
+                    for (int i = 0; i < NB; i++) cb[i] = q[((1 + i) * BS_CAP + e) * 64 + lane];
+                    const uint32_t meta = q[((NB + 1) * BS_CAP + e) * 64 + lane];
+                    consume_hits<W, NB>(h, cb, (int)(meta & 2047u), (int)((meta >> 11) & 63u),
+                                        (int)((meta >> 17) & 1u), s0, T, nB, wtA, wtB, acc);
+                }
+            }
+            qn = 0;
+        };
+
+        for (int strand = 0; strand < 2; strand++) {
+            /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
+             * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
+            const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 3) * A.xw);
+            const sgpr_words sbl = sbh + A.xw;
+            const sgpr_words sbv = sbl + A.xw;
+            for (int d0 = 0; d0 < T; d0 += BS_DU) {
+                uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1], bv[BS_DU + W - 1];
+#pragma unroll
+                for (int i = 0; i < BS_DU + W - 1; i++) {
+                    bh[i] = sbh[d0 + i];
+                    bl[i] = sbl[d0 + i];
+                    bv[i] = sbv[d0 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < BS_DU; u++) {
+                    if (d0 + u < T) {
+                        Count<NB> cnt[W];
+                        window_counts<W, L, NB>(Ahi, Alo, bh + u, bl + u, cnt);
+#pragma unroll
+                        for (int w = 0; w < W; w++) {
+                            const uint32_t h = count_le<NB, D>(cnt[w]) & AV[w] & bv[u + w];
+                            if (h) {
+                                q[(0 * BS_CAP + qn) * 64 + lane] = h;
+#pragma unroll
+                                for (int i = 0; i < NB; i++) q[((1 + i) * BS_CAP + qn) * 64 + lane] = cnt[w].b[i];
+                                q[((NB + 1) * BS_CAP + qn) * 64 + lane] = pack_meta(d0 + u, w, strand);
+                                qn++;
+                            }
+                        }
+                        if (__any(qn > BS_CAP - W)) drain();
+                    }
+                }
+            }
+        }
+        drain();
+
+        /* a sequence longer than one segment occupies consecutive lanes: fold them */
+        if (A.maxseg > 1) {
+            uint32_t own[NACC];
+#pragma unroll
+            for (int k = 0; k < NACC; k++) own[k] = acc[k];
+            for (int s = 1; s < A.maxseg; s++) {
+                const int other = __shfl_down(myseq, s);
+                const bool same = (lane + s < 64) && (other == myseq) && (myseq >= 0);
+#pragma unroll
+                for (int k = 0; k < NACC; k++) {
+                    const uint32_t t = __shfl_down(own[k], s);
+                    if (same) acc[k] += t;
+                }
+            }
+        }
+
+        if (myseq >= 0 && s0 == 0 && j <= myseq) {
+            /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
+            double g = 0.0;
+#pragma unroll
+            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)acc[m];
+            const int64_t r = A.out.local_rows ? slot : myseq;
+            A.out.G[r * A.out.ld + j] = g;
+            if (A.out.P) {
+#pragma unroll
+                for (int m = 0; m <= D; m++) A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)acc[m];
+            }
+        }
+    }
+}
+
+struct DirectArgs {
+    const int *rows;
+    int nrows;
+    const int *len;
+    const int64_t *lmoff;
+    const uint32_t *lmf, *lmr;
+    const uint8_t *wt;
+    double c[GKM_MAXD1];
+    GramOut out;
+    int cj, L, d;
+};
+
+/*
+ * General fallback (any L <= 12, d <= 12): lane = row sequence, R row l-mers held in
+ * registers, the column strand's packed l-mers streamed as wave-uniform scalars;
+ * XOR / fold / popcount per comparison, rare exec-masked accumulate.
+ */
+template <bool WEIGHTED>
+__global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
+{
+    constexpr int R = 8;
+    __shared__ uint32_t acc[GKM_MAXD1][64];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.y;
+    const int ridx = tile * 64 + lane;
+    const int a = ridx < A.nrows ? A.rows[ridx] : -1;
+    const int amax = A.rows[min(tile * 64 + 63, A.nrows - 1)];
+    const int j0 = blockIdx.x * A.cj;
+    const int j1 = min(j0 + A.cj, amax + 1);
+    if (j0 >= j1) return;
+    const int d = A.d;
+    const int na = a >= 0 ? A.len[a] - A.L + 1 : 0;
+    const int64_t offa = a >= 0 ? A.lmoff[a] : 0;
+    int namax = na;
+    for (int s = 32; s >= 1; s >>= 1) namax = max(namax, __shfl_xor(namax, s));
+
+    for (int j = j0; j < j1; j++) {
+        const int nj = A.len[j] - A.L + 1;
+        const int64_t offj = A.lmoff[j];
+        for (int m = 0; m <= d; m++) acc[m][lane] = 0u;
+        for (int p0 = 0; p0 < namax; p0 += R) {
+            uint32_t u[R], wu[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool ok = (p0 + r) < na;
+                u[r] = ok ? A.lmf[offa + p0 + r] : 0u;
+                wu[r] = ok ? (WEIGHTED ? (uint32_t)A.wt[offa + p0 + r] : 1u) : 0u; /* padding adds 0 */
+            }
+            for (int qi = 0; qi < nj; qi++) {
+                const uint32_t xf = A.lmf[offj + qi], xr = A.lmr[offj + qi];
+                const uint32_t wf = WEIGHTED ? (uint32_t)A.wt[offj + qi] : 1u;
+                const uint32_t wr = WEIGHTED ? (uint32_t)A.wt[offj + nj - 1 - qi] : 1u; /* libgkm.c:924 */
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    uint32_t t = u[r] ^ xf;
+                    t = (t | (t >> 1)) & 0x55555555u;
+                    int m = __popc(t);
+                    if (m <= d) acc[m][lane] += wu[r] * wf;
+                    t = u[r] ^ xr;
+                    t = (t | (t >> 1)) & 0x55555555u;
+                    m = __popc(t);
+                    if (m <= d) acc[m][lane] += wu[r] * wr;
+                }
+            }
+        }
+        if (a >= 0 && j <= a) {
+            double g = 0.0;
+            for (int m = 0; m <= d; m++) g += A.c[m] * (double)(int32_t)acc[m][lane];
+            const int64_t r = A.out.local_rows ? ridx : a;
+            A.out.G[r * A.out.ld + j] = g;
+            if (A.out.P)
+                for (int m = 0; m <= d; m++) A.out.P[(r * A.out.ldp + j) * (d + 1) + m] = (int32_t)acc[m][lane];
+        }
+    }
+}
+
+/* ------------------------------------------------------------ normalise */
+__global__ void k_sqnorm(const double *__restrict__ G, int64_t ld, int n, double *__restrict__ sq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sq[i] = sqrt(G[(int64_t)i * ld + i]); /* libgkm.c:753-758 */
+}
+
+/* K(a,j) = G(a,j) / (sq_a * sq_j): product first, one division (libgkm.c:1169-1172);
+ * RBF types: exp(gamma (K-1)) (:1175-1179); K(a,a) = 1.0 (gkmkern_pylib.c:218-221) */
+__global__ void k_normalize(double *__restrict__ G, int64_t ld, int n, const double *__restrict__ sq,
+                            int rbf, double gamma, int symmetric)
+{
+    const int a = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > a || j >= n) return;
+    double v;
+    if (j == a) {
+        v = 1.0;
+    } else {
+        v = G[(int64_t)a * ld + j] / (sq[a] * sq[j]);
+        if (rbf) v = exp(gamma * (v - 1));
+        if (symmetric) G[(int64_t)j * ld + a] = v;
+    }
+    G[(int64_t)a * ld + j] = v;
+}
+
+/* ---------------------------------------------------------- host: upload */
+extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
+                                    const uint8_t *wt, const int64_t *wt_offsets, int weighted,
+                                    void *stream_)
+{
+    if (!ctx || n <= 0 || !codes || !offsets) return set_err_msg("gkmhip_set_sequences: bad arguments", 2);
+    if (weighted && (!wt || !wt_offsets)) return set_err_msg("weighted kernel needs weights", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = ctx->L;
+    ctx->n = n;
+    ctx->weighted = weighted ? 1 : 0;
+    ctx->h_len.resize((size_t)n);
+    ctx->h_lmoff.resize((size_t)n + 1);
+    ctx->h_cum_n.resize((size_t)n + 1);
+    ctx->h_lmoff[0] = 0;
+    ctx->h_cum_n[0] = 0.0;
+    ctx->maxlen = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (len < L) return set_err_msg("sequence " + std::to_string(i) + " is shorter than L", 3);
+        if (len > 2047) return set_err_msg("sequence longer than 2047", 3);
+        ctx->h_len[(size_t)i] = (int)len;
+        ctx->h_lmoff[(size_t)i + 1] = ctx->h_lmoff[(size_t)i] + (len - L + 1);
+        ctx->h_cum_n[(size_t)i + 1] = ctx->h_cum_n[(size_t)i] + (double)(len - L + 1);
+        ctx->maxlen = std::max(ctx->maxlen, (int)len);
+        if (weighted && wt_offsets[i + 1] - wt_offsets[i] != len - L + 1)
+            return set_err_msg("weight table does not match sequence lengths", 3);
+    }
+    const size_t total = (size_t)offsets[n], total_lm = (size_t)ctx->h_lmoff[(size_t)n];
+    if (ctx->codes.ensure(total) || ctx->off.ensure((size_t)n + 1) || ctx->lmoff.ensure((size_t)n + 1) ||
+        ctx->len.ensure((size_t)n) || ctx->wt.ensure(total_lm))
+        return 4;
+    HIPCHK(hipMemcpyAsync(ctx->codes.p, codes, total, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->off.p, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->lmoff.p, ctx->h_lmoff.data(), ((size_t)n + 1) * sizeof(int64_t),
+                          hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->len.p, ctx->h_len.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (weighted) {
+        if (wt_offsets[0] != 0) return set_err_msg("wt_offsets[0] must be 0", 3);
+        HIPCHK(hipMemcpyAsync(ctx->wt.p, wt, total_lm, hipMemcpyHostToDevice, stream));
+    } else {
+        HIPCHK(hipMemsetAsync(ctx->wt.p, 1, total_lm, stream));
+    }
+    ctx->have_lmers = false;
+    ctx->have_sb = false;
+    return 0;
+}
+
+static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->have_lmers) return 0;
+    const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
+    if (ctx->lmf.ensure(total_lm) || ctx->lmr.ensure(total_lm)) return 4;
+    hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
+                       ctx->lmoff.p, ctx->L, ctx->lmf.p, ctx->lmr.p);
+    HIPCHK(hipGetLastError());
+    ctx->have_lmers = true;
+    return 0;
+}
+
+static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
+{
+    if (ctx->have_sb && ctx->sb_W == W) return 0;
+    const int xw = ((ctx->maxlen + W + BS_DU + 15) / 16) * 16;
+    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw)) return 4;
+    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 3), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
+                       W, ctx->L, xw, ctx->sb.p);
+    HIPCHK(hipGetLastError());
+    ctx->sb_xw = xw;
+    ctx->sb_W = W;
+    ctx->have_sb = true;
+    return 0;
+}
+
+/* ------------------------------------------------- host: launch dispatch */
+typedef void (*bs_kernel_t)(const BsArgs);
+
+template <int W>
+static bs_kernel_t pick_bitslice(int L, int d, bool weighted)
+{
+#define GKM_BS(LL, DD) \
+    if (L == LL && d == DD) return weighted ? k_gram_bitslice<W, LL, DD, true> : k_gram_bitslice<W, LL, DD, false>;
+    GKM_BS(10, 3)
+    GKM_BS(11, 3)
+    GKM_BS(12, 4)
+    GKM_BS(8, 4)
+    GKM_BS(9, 4)
+    GKM_BS(4, 2)
+    GKM_BS(12, 6)
+#undef GKM_BS
+    return nullptr;
+}
+
+constexpr int BS_W = 10;
+
+extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                int64_t ld, int32_t *P, int64_t ldp, void *stream_)
+{
+    if (!ctx || !rows || nrows <= 0 || !G) return set_err_msg("gkmhip_gram_rows: bad arguments", 2);
+    if (ctx->n <= 0) return set_err_msg("gkmhip_gram_rows: no sequences uploaded", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = ctx->L, d = ctx->d, n = ctx->n;
+    double comparisons = 0;
+    for (int i = 0; i < nrows; i++) {
+        if (rows[i] < 0 || rows[i] >= n || (i > 0 && rows[i] <= rows[i - 1]))
+            return set_err_msg("rows must be strictly ascending sequence indices", 2);
+        const double na = (double)(ctx->h_len[(size_t)rows[i]] - L + 1);
+        comparisons += 2.0 * na * ctx->h_cum_n[(size_t)rows[i] + 1];
+    }
+    if (ld <= rows[nrows - 1]) return set_err_msg("leading dimension too small", 2);
+    const int amax_all = rows[nrows - 1];
+
+    GramOut out;
+    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows;
+
+    bs_kernel_t bs = nullptr;
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs = pick_bitslice<BS_W>(L, d, ctx->weighted != 0);
+    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs)
+        return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
+
+    if (bs) {
+        const int W = BS_W;
+        const int cap = gkmbs::segment_capacity(W, L);
+        if (ensure_sb(ctx, W, stream)) return 4;
+        /* lay the rows out as tiles of 64 segments; all segments of one sequence share a tile */
+        std::vector<int> seg_seq, seg_s0, seg_slot, tile_amax;
+        int maxseg = 1;
+        for (int i = 0; i < nrows; i++) {
+            const int a = rows[i];
+            const int nwin = ctx->h_len[(size_t)a] - L + 1;
+            const int nseg = (nwin + cap - 1) / cap;
+            maxseg = std::max(maxseg, nseg);
+            const int used = (int)(seg_seq.size() % 64);
+            if (used + nseg > 64)
+                for (int k = used; k < 64; k++) { seg_seq.push_back(-1); seg_s0.push_back(0); seg_slot.push_back(0); }
+            for (int k = 0; k < nseg; k++) { seg_seq.push_back(a); seg_s0.push_back(k * cap); seg_slot.push_back(i); }
+        }
+        while (seg_seq.size() % 64) { seg_seq.push_back(-1); seg_s0.push_back(0); seg_slot.push_back(0); }
+        const int ntiles = (int)(seg_seq.size() / 64);
+        tile_amax.assign((size_t)ntiles, -1);
+        for (size_t k = 0; k < seg_seq.size(); k++)
+            tile_amax[k / 64] = std::max(tile_amax[k / 64], seg_seq[k]);
+        if (ctx->seg_seq.ensure(seg_seq.size()) || ctx->seg_s0.ensure(seg_seq.size()) ||
+            ctx->seg_slot.ensure(seg_seq.size()) || ctx->tile_amax.ensure((size_t)ntiles) ||
+            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64))
+            return 4;
+        HIPCHK(hipMemcpyAsync(ctx->seg_seq.p, seg_seq.data(), seg_seq.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->seg_s0.p, seg_s0.data(), seg_s0.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->seg_slot.p, seg_slot.data(), seg_slot.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, tile_amax.data(), tile_amax.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        /* the host vectors above are pageable: the copies have completed on return */
+        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
+                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p);
+        HIPCHK(hipGetLastError());
+
+        BsArgs A;
+        A.rowplanes = ctx->rowplanes.p;
+        A.seg_seq = ctx->seg_seq.p; A.seg_s0 = ctx->seg_s0.p; A.seg_slot = ctx->seg_slot.p;
+        A.tile_amax = ctx->tile_amax.p;
+        A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.wt = ctx->wt.p;
+        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+        A.out = out;
+        A.cj = 16;
+        A.maxseg = maxseg;
+        const char *e = getenv("GKM_CJ");
+        if (e && atoi(e) > 0) A.cj = atoi(e);
+        const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
+        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipLaunchKernelGGL(bs, dim3(nchunks, (unsigned)ntiles), dim3(64), 0, stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        ctx->last_kernel = "k_gram_bitslice";
+    } else {
+        if (ensure_lmers(ctx, stream)) return 4;
+        if (ctx->rows.ensure((size_t)nrows)) return 4;
+        HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+        DirectArgs A;
+        A.rows = ctx->rows.p; A.nrows = nrows;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.wt = ctx->wt.p;
+        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+        A.out = out;
+        A.cj = 16; A.L = L; A.d = d;
+        const unsigned ntiles = (unsigned)((nrows + 63) / 64);
+        const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
+        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        if (ctx->weighted) hipLaunchKernelGGL(k_gram_direct<true>, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
+        else hipLaunchKernelGGL(k_gram_direct<false>, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        ctx->last_kernel = "k_gram_direct";
+    }
+    ctx->ev_valid = true;
+    ctx->last_comparisons = comparisons;
+    return 0;
+}
+
+extern "C" int gkmhip_normalize(gkmhip_ctx *ctx, double *G, int64_t ld, double *sqnorm, int symmetric,
+                                void *stream_)
+{
+    if (!ctx || !G || ctx->n <= 0) return set_err_msg("gkmhip_normalize: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    double *sq = sqnorm;
+    if (!sq) {
+        if (ctx->sq.ensure((size_t)n)) return 4;
+        sq = ctx->sq.p;
+    }
+    hipLaunchKernelGGL(k_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, G, ld, n, sq);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_normalize, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, G, ld,
+                       n, sq, ctx->rbf, ctx->gamma, symmetric);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* ------------------------------------------------------- memory helpers */
+extern "C" void *gkmhip_malloc(int device, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { set_err("hipMalloc", e, __FILE__, __LINE__); return nullptr; }
+    return p;
+}
+extern "C" void gkmhip_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int gkmhip_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int gkmhip_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int gkmhip_sync(void *stream)
+{
+    if (stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    else HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+/* Lower triangle of a device matrix into caller-owned host rows, through two pinned
+ * staging buffers: the D2H DMA of block k+1 overlaps the host scatter of block k. */
+extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64_t ld, int n, double **rows,
+                                         int nthreads)
+{
+    if (!ctx || !K || !rows || n <= 0) return set_err_msg("gkmhip_copy_lower_to_rows: bad arguments", 2);
+    HIPCHK(hipSetDevice(ctx->device));
+    const size_t want = (size_t)64 << 20;
+    if (ctx->stage_bytes < want) {
+        for (int i = 0; i < 2; i++) {
+            if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
+            ctx->stage[i] = nullptr;
+            HIPCHK(hipHostMalloc((void **)&ctx->stage[i], want, hipHostMallocDefault));
+        }
+        ctx->stage_bytes = want;
+    }
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+    hipStream_t s;
+    HIPCHK(hipStreamCreate(&s));
+    struct Blk { int r0, r1; };
+    std::vector<Blk> blocks;
+    for (int r0 = 0; r0 < n;) {
+        /* rows r0..r1-1, each copied with width r1 (elements): r1*(r1-r0)*8 <= want */
+        int r1 = r0 + 1;
+        while (r1 < n && (size_t)(r1 + 1) * (size_t)(r1 + 1 - r0) * 8 <= want) r1++;
+        blocks.push_back({r0, r1});
+        r0 = r1;
+    }
+    auto issue = [&](size_t b) -> hipError_t {
+        const Blk &k = blocks[b];
+        return hipMemcpy2DAsync(ctx->stage[b & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
+                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, s);
+    };
+    hipError_t e = issue(0);
+    for (size_t b = 0; e == hipSuccess && b < blocks.size(); b++) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) break;
+        if (b + 1 < blocks.size()) e = issue(b + 1);
+        const Blk &k = blocks[b];
+        const double *src = ctx->stage[b & 1];
+        auto work = [&](int t) {
+            for (int r = k.r0 + t; r < k.r1; r += nthreads)
+                memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));
+        };
+        if (nthreads == 1 || k.r1 - k.r0 < 64) {
+            for (int t = 0; t < nthreads; t++) work(t);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+    }
+    (void)hipStreamSynchronize(s);
+    (void)hipStreamDestroy(s);
+    if (e != hipSuccess) return set_err("copy_lower_to_rows", e, __FILE__, __LINE__);
+    return 0;
+}
+
+extern "C" double gkmhip_last_kernel_ms(gkmhip_ctx *ctx)
+{
+    if (!ctx || !ctx->ev_valid) return -1.0;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+extern "C" double gkmhip_last_comparisons(gkmhip_ctx *ctx) { return ctx ? ctx->last_comparisons : 0.0; }
+extern "C" const char *gkmhip_last_kernel_name(gkmhip_ctx *ctx) { return ctx ? ctx->last_kernel : "none"; }

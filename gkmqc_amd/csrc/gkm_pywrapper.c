@@ -1,0 +1,177 @@
+/*
+ * gkm_pywrapper.c -- the drop-in C-ABI entry point (include/gkmkern_pylib.h).
+ *
+ * Thin C host: options -> host tables (c_m, positional weights) -> FASTA -> device
+ * layer (include/gkm_hip.h) -> the caller's row pointers.  Replaces the reference's
+ * src/gkmkern_pylib.c:92-246; the k-mer tree and the pthread row loop are gone, the
+ * rows are computed on the GPU.  There is NO CPU compute path: without a usable HIP
+ * device the call logs an ERROR and returns non-zero.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "../../include/gkm_hip.h"
+#include "gkm_host.h"
+
+static double now_ms(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
+}
+
+int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
+{
+    int rc = 1;
+    gkm_problem *prob = NULL;
+    gkmhip_ctx *ctx = NULL;
+    double *dG = NULL;
+    uint8_t *wt = NULL;
+    int64_t *wt_off = NULL;
+    int *rows = NULL;
+    const double t_start = now_ms();
+
+    if (!opts || !kmat || !kmat_size) return 1;
+
+    const int level = gkm_log_level_from_verbosity(opts->verbosity);
+    if (level < 0) { /* the reference prints this and calls exit(0), gkmkern_pylib.c:135-137 */
+        fprintf(stderr, "Unknown verbosity: %d\n", opts->verbosity);
+        return 1;
+    }
+    gkm_log_set_level(level);
+
+    const int kt = opts->kernel_type, L = opts->L, k = opts->k, d = opts->d;
+    const int weighted = (kt == EST_TRUNC_PW || kt == EST_TRUNC_PW_RBF);
+    const int rbf = (kt == EST_TRUNC_RBF || kt == EST_TRUNC_PW_RBF);
+
+    /* same INFO lines as gkmkern_pylib.c:140-155 */
+    gkm_log(GKM_LOG_INFO, "Arguments:");
+    gkm_log(GKM_LOG_INFO, "  posfile = %s", opts->posfile ? opts->posfile : "(null)");
+    gkm_log(GKM_LOG_INFO, "  negfile = %s", opts->negfile ? opts->negfile : "(null)");
+    gkm_log(GKM_LOG_INFO, "Parameters:");
+    gkm_log(GKM_LOG_INFO, "  kernel-type = %d", kt);
+    gkm_log(GKM_LOG_INFO, "  L = %d", L);
+    gkm_log(GKM_LOG_INFO, "  k = %d", k);
+    gkm_log(GKM_LOG_INFO, "  d = %d", d);
+    if (rbf) gkm_log(GKM_LOG_INFO, "  gamma = %g", opts->gamma);
+    if (weighted) {
+        gkm_log(GKM_LOG_INFO, "  M = %d", opts->M);
+        gkm_log(GKM_LOG_INFO, "  H = %g", opts->H);
+    }
+
+    const char *bad = gkm_check_parameter_values(kt, L, k, d);
+    if (bad) {
+        gkm_log(GKM_LOG_ERROR, "%s", bad);
+        return 1;
+    }
+    if (!opts->posfile || !opts->negfile) {
+        gkm_log(GKM_LOG_ERROR, "can't open file");
+        return 1;
+    }
+
+    double c[GKM_MAX_L + 1];
+    gkm_mismatch_weights(kt, L, k, c);
+    gkm_log(GKM_LOG_DEBUG, "gkm-kernel weights:");
+    for (int m = 0; m <= d; m++) gkm_log(GKM_LOG_DEBUG, "  c[%d] = %.6f", m, c[m]);
+
+    prob = gkm_problem_read(opts->posfile, opts->negfile);
+    if (!prob) {
+        gkm_log(GKM_LOG_ERROR, "can't open file");
+        return 1;
+    }
+    const int n = gkm_problem_size(prob), n_pos = gkm_problem_npos(prob);
+    gkm_log(GKM_LOG_INFO, "read %d sequences from %s", n_pos, opts->posfile);
+    gkm_log(GKM_LOG_INFO, "read %d sequences from %s", n - n_pos, opts->negfile);
+    if (n_pos == 0 || n == n_pos) {
+        gkm_log(GKM_LOG_ERROR, "no sequences in %s", n_pos == 0 ? opts->posfile : opts->negfile);
+        goto done;
+    }
+    if (gkm_problem_invalid_chars(prob) > 0)
+        gkm_log(GKM_LOG_WARN, "%ld characters are not valid nucleotides and were read as 'A'. Only ACGT are allowed",
+                gkm_problem_invalid_chars(prob));
+    if (gkm_problem_truncated(prob) > 0)
+        gkm_log(GKM_LOG_WARN, "maximum sequence length allowed is %d. Only the first %d nucleotides of %ld longer sequence(s) are used",
+                GKM_MAX_SEQ, GKM_MAX_SEQ, gkm_problem_truncated(prob));
+
+    /* positional weights, one table per distinct l-mer count, expanded per sequence */
+    wt_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
+    if (!wt_off) goto done;
+    wt_off[0] = 0;
+    for (int i = 0; i < n; i++) {
+        const int len = gkm_problem_seqlen(prob, i);
+        if (len < L) { /* undefined behaviour in the reference (negative l-mer count) */
+            gkm_log(GKM_LOG_ERROR, "sequence %d has %d nucleotides, fewer than L = %d", i, len, L);
+            goto done;
+        }
+        wt_off[i + 1] = wt_off[i] + (len - L + 1);
+    }
+    if (weighted) {
+        uint8_t *table[GKM_MAX_SEQ + 1];
+        memset(table, 0, sizeof table);
+        wt = (uint8_t *)malloc((size_t)wt_off[n]);
+        if (!wt) goto done;
+        for (int i = 0; i < n; i++) {
+            const int nl = gkm_problem_seqlen(prob, i) - L + 1;
+            if (!table[nl]) {
+                table[nl] = (uint8_t *)malloc((size_t)nl);
+                if (!table[nl]) goto done;
+                gkm_position_weights(kt, nl, opts->M, opts->H, table[nl]);
+            }
+            memcpy(wt + wt_off[i], table[nl], (size_t)nl);
+        }
+        for (int i = 0; i <= GKM_MAX_SEQ; i++) free(table[i]);
+    }
+    const double t_parsed = now_ms();
+
+    int device = 0;
+    const char *env = getenv("GKM_DEVICE");
+    if (env) device = atoi(env);
+    ctx = gkmhip_create(device, L, d, c, rbf, opts->gamma);
+    if (!ctx) {
+        gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
+        goto done;
+    }
+    if (gkmhip_set_sequences(ctx, n, gkm_problem_all_codes(prob), gkm_problem_offsets(prob), wt, wt_off, weighted,
+                             NULL)) {
+        gkm_log(GKM_LOG_ERROR, "device upload failed: %s", gkmhip_last_error());
+        goto done;
+    }
+    dG = (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
+    if (!dG) {
+        gkm_log(GKM_LOG_ERROR, "device allocation of the %d x %d matrix failed: %s", n, n, gkmhip_last_error());
+        goto done;
+    }
+    rows = (int *)malloc(sizeof(int) * (size_t)n);
+    if (!rows) goto done;
+    for (int i = 0; i < n; i++) rows[i] = i;
+    if (gkmhip_gram_rows(ctx, rows, n, 0, dG, n, NULL, 0, NULL) || gkmhip_normalize(ctx, dG, n, NULL, 0, NULL) ||
+        gkmhip_sync(NULL)) {
+        gkm_log(GKM_LOG_ERROR, "gram kernel failed: %s", gkmhip_last_error());
+        goto done;
+    }
+    const double t_kernel = now_ms();
+    gkm_log(GKM_LOG_DEBUG, "%s: %.3f ms on device for %.4g l-mer comparisons", gkmhip_last_kernel_name(ctx),
+            gkmhip_last_kernel_ms(ctx), gkmhip_last_comparisons(ctx));
+
+    /* rows a: K(a, 0..a-1) and the unit diagonal -- exactly the cells the reference writes */
+    if (gkmhip_copy_lower_to_rows(ctx, dG, n, n, kmat, opts->nthreads > 0 ? opts->nthreads : 1)) {
+        gkm_log(GKM_LOG_ERROR, "device to host copy failed: %s", gkmhip_last_error());
+        goto done;
+    }
+    kmat_size[0] = n_pos;
+    kmat_size[1] = n - n_pos;
+    rc = 0;
+    gkm_log(GKM_LOG_DEBUG, "timing: read+tables %.1f ms, device %.1f ms, copy-out %.1f ms", t_parsed - t_start,
+            t_kernel - t_parsed, now_ms() - t_kernel);
+
+done:
+    free(rows);
+    if (dG) gkmhip_free(dG);
+    if (ctx) gkmhip_destroy(ctx);
+    free(wt);
+    free(wt_off);
+    gkm_problem_free(prob);
+    return rc;
+}

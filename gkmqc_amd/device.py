@@ -1,0 +1,266 @@
+"""ctypes binding of the C ABI exported by ``bin/gkmkern_pylib.so``.
+
+Two layers, both declared under ``include/``:
+  * ``gkm_main_pywrapper`` -- the drop-in boundary (include/gkmkern_pylib.h), bound exactly
+    as the reference binds it (scripts/gkmsvm.py:48-61,85-88);
+  * ``gkmhip_*`` -- the device layer (include/gkm_hip.h) used by bench.py and the GPU tests
+    with device memory and streams supplied by PyTorch-ROCm.
+
+There is no CPU compute path here: if the shared object is missing the import of the
+library fails loudly, and on a box without a GPU the device calls return errors.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(HERE, "bin")
+LIB_NAME = "gkmkern_pylib.so"
+
+KERNEL_AUTO, KERNEL_DIRECT, KERNEL_BITSLICE = 0, 1, 2
+
+
+class gkmOpt(ctypes.Structure):
+    """Same layout as the reference's gkmOpt (src/libgkm.h:149-161)."""
+    _fields_ = (
+        ("kernel_type", ctypes.c_int), ("L", ctypes.c_int), ("k", ctypes.c_int), ("d", ctypes.c_int),
+        ("M", ctypes.c_uint8), ("H", ctypes.c_double), ("gamma", ctypes.c_double),
+        ("posfile", ctypes.c_char_p), ("negfile", ctypes.c_char_p),
+        ("nthreads", ctypes.c_int), ("verbosity", ctypes.c_int),
+    )
+
+
+class GkmError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path():
+    return os.path.join(LIB_DIR, LIB_NAME)
+
+
+def load():
+    """Load (once) and prototype the shared object.  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise GkmError("%s is missing: build it with `make -C gkmqc_amd/csrc` "
+                       "(or `python -c 'import __graft_entry__ as g; g.build()'`)" % path)
+    L = ctypes.CDLL(path)
+    vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+    L.gkm_main_pywrapper.restype = i32
+    L.gkm_main_pywrapper.argtypes = (ctypes.POINTER(gkmOpt), vp, vp)
+    L.gkm_check_parameter_values.restype = ctypes.c_char_p
+    L.gkm_check_parameter_values.argtypes = (i32, i32, i32, i32)
+    L.gkm_mismatch_weights.restype = i32
+    L.gkm_mismatch_weights.argtypes = (i32, i32, i32, vp)
+    L.gkm_position_weights.restype = None
+    L.gkm_position_weights.argtypes = (i32, i32, ctypes.c_uint8, dbl, vp)
+    L.gkm_problem_read.restype = vp
+    L.gkm_problem_read.argtypes = (ctypes.c_char_p, ctypes.c_char_p)
+    L.gkm_problem_free.restype = None
+    L.gkm_problem_free.argtypes = (vp,)
+    for name in ("gkm_problem_size", "gkm_problem_npos"):
+        getattr(L, name).restype = i32
+        getattr(L, name).argtypes = (vp,)
+    L.gkm_problem_seqlen.restype = i32
+    L.gkm_problem_seqlen.argtypes = (vp, i32)
+    L.gkm_problem_codes.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.gkm_problem_codes.argtypes = (vp, i32)
+    for name in ("gkm_problem_invalid_chars", "gkm_problem_truncated"):
+        getattr(L, name).restype = ctypes.c_long
+        getattr(L, name).argtypes = (vp,)
+
+    L.gkmhip_last_error.restype = ctypes.c_char_p
+    L.gkmhip_device_count.restype = i32
+    L.gkmhip_create.restype = vp
+    L.gkmhip_create.argtypes = (i32, i32, i32, vp, i32, dbl)
+    L.gkmhip_destroy.restype = None
+    L.gkmhip_destroy.argtypes = (vp,)
+    L.gkmhip_set_kernel.restype = i32
+    L.gkmhip_set_kernel.argtypes = (vp, i32)
+    L.gkmhip_set_sequences.restype = i32
+    L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, vp, i32, vp)
+    L.gkmhip_gram_rows.restype = i32
+    L.gkmhip_gram_rows.argtypes = (vp, vp, i32, i32, vp, i64, vp, i64, vp)
+    L.gkmhip_normalize.restype = i32
+    L.gkmhip_normalize.argtypes = (vp, vp, i64, vp, i32, vp)
+    L.gkmhip_malloc.restype = vp
+    L.gkmhip_malloc.argtypes = (i32, ctypes.c_size_t)
+    L.gkmhip_free.restype = None
+    L.gkmhip_free.argtypes = (vp,)
+    L.gkmhip_memcpy_d2h.restype = i32
+    L.gkmhip_memcpy_d2h.argtypes = (vp, vp, ctypes.c_size_t)
+    L.gkmhip_memcpy_h2d.restype = i32
+    L.gkmhip_memcpy_h2d.argtypes = (vp, vp, ctypes.c_size_t)
+    L.gkmhip_sync.restype = i32
+    L.gkmhip_sync.argtypes = (vp,)
+    L.gkmhip_copy_lower_to_rows.restype = i32
+    L.gkmhip_copy_lower_to_rows.argtypes = (vp, vp, i64, i32, vp, i32)
+    L.gkmhip_last_kernel_ms.restype = dbl
+    L.gkmhip_last_kernel_ms.argtypes = (vp,)
+    L.gkmhip_last_comparisons.restype = dbl
+    L.gkmhip_last_comparisons.argtypes = (vp,)
+    L.gkmhip_last_kernel_name.restype = ctypes.c_char_p
+    L.gkmhip_last_kernel_name.argtypes = (vp,)
+    _lib = L
+    return L
+
+
+# ------------------------------------------------------------------ host tables
+def check_parameters(kernel_type, L, k, d):
+    msg = load().gkm_check_parameter_values(kernel_type, L, k, d)
+    return msg.decode() if msg else None
+
+
+def mismatch_weights(kernel_type, L, k):
+    out = np.zeros(L + 1, dtype=np.float64)
+    if load().gkm_mismatch_weights(kernel_type, L, k, out.ctypes.data):
+        raise GkmError("invalid (kernel_type, L, k)")
+    return out
+
+
+def position_weights(kernel_type, n, M=50, H=50.0):
+    out = np.zeros(max(n, 0), dtype=np.uint8)
+    load().gkm_position_weights(kernel_type, n, M, float(H), out.ctypes.data)
+    return out
+
+
+def read_problem(posfile, negfile):
+    """FASTA pair -> (list of uint8 base-code arrays, n_pos, n_invalid_chars, n_truncated)."""
+    L = load()
+    h = L.gkm_problem_read(os.fsencode(posfile), os.fsencode(negfile))
+    if not h:
+        raise GkmError("cannot read %s / %s" % (posfile, negfile))
+    try:
+        n = L.gkm_problem_size(h)
+        seqs = []
+        for i in range(n):
+            ln = L.gkm_problem_seqlen(h, i)
+            ptr = L.gkm_problem_codes(h, i)
+            seqs.append(np.ctypeslib.as_array(ptr, shape=(ln,)).copy() if ln else np.zeros(0, np.uint8))
+        return seqs, L.gkm_problem_npos(h), L.gkm_problem_invalid_chars(h), L.gkm_problem_truncated(h)
+    finally:
+        L.gkm_problem_free(h)
+
+
+def encode(seq):
+    """bytes/str of ACGT (any case; other characters count as A) -> uint8 codes 0..3."""
+    if isinstance(seq, str):
+        seq = seq.encode()
+    lut = np.zeros(256, dtype=np.uint8)
+    for ch, v in ((b"C", 1), (b"G", 2), (b"T", 3), (b"c", 1), (b"g", 2), (b"t", 3)):
+        lut[ch[0]] = v
+    return lut[np.frombuffer(seq, dtype=np.uint8)]
+
+
+# ------------------------------------------------------------------ device layer
+class GramContext:
+    """Owns one gkmhip_ctx: parameters + uploaded sequences on one GPU."""
+
+    def __init__(self, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0):
+        bad = check_parameters(kernel_type, L, k, d)
+        if bad:
+            raise GkmError(bad)
+        self.lib = load()
+        self.kernel_type, self.L, self.k, self.d, self.M, self.H, self.gamma = kernel_type, L, k, d, M, H, gamma
+        self.weighted = kernel_type in (4, 5)
+        self.rbf = kernel_type in (3, 5)
+        self.c = mismatch_weights(kernel_type, L, k)
+        self.device = device
+        self.n = 0
+        self.handle = self.lib.gkmhip_create(device, L, d, self.c.ctypes.data, int(self.rbf), float(gamma))
+        if not self.handle:
+            raise GkmError("gkmhip_create: " + self.lib.gkmhip_last_error().decode())
+
+    def _chk(self, rc, what):
+        if rc:
+            raise GkmError("%s failed (%d): %s" % (what, rc, self.lib.gkmhip_last_error().decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.gkmhip_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_kernel(self, which):
+        self._chk(self.lib.gkmhip_set_kernel(self.handle, which), "gkmhip_set_kernel")
+
+    def set_sequences(self, seqs, stream=0):
+        """seqs: list of uint8 arrays of base codes 0..3."""
+        n = len(seqs)
+        lens = np.array([len(s) for s in seqs], dtype=np.int64)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        codes = np.concatenate(seqs).astype(np.uint8) if n else np.zeros(0, np.uint8)
+        wt = wt_off = None
+        if self.weighted:
+            nl = lens - self.L + 1
+            if (nl <= 0).any():
+                raise GkmError("a sequence is shorter than L")
+            wt_off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(nl, out=wt_off[1:])
+            tables = {int(v): position_weights(self.kernel_type, int(v), self.M, self.H) for v in np.unique(nl)}
+            wt = np.concatenate([tables[int(v)] for v in nl])
+        self._keep = (codes, off, wt, wt_off)
+        self._chk(self.lib.gkmhip_set_sequences(
+            self.handle, n, codes.ctypes.data, off.ctypes.data,
+            wt.ctypes.data if wt is not None else None, wt_off.ctypes.data if wt_off is not None else None,
+            int(self.weighted), stream), "gkmhip_set_sequences")
+        self.n = n
+        self.lens = lens
+
+    def gram_rows(self, rows, G_ptr, ld, P_ptr=None, ldp=0, local_rows=True, stream=0):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self._chk(self.lib.gkmhip_gram_rows(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr, ld,
+                                            P_ptr, ldp, stream), "gkmhip_gram_rows")
+
+    def normalize(self, G_ptr, ld, sq_ptr=None, symmetric=False, stream=0):
+        self._chk(self.lib.gkmhip_normalize(self.handle, G_ptr, ld, sq_ptr, int(symmetric), stream),
+                  "gkmhip_normalize")
+
+    def last_kernel_ms(self):
+        return self.lib.gkmhip_last_kernel_ms(self.handle)
+
+    def last_comparisons(self):
+        return self.lib.gkmhip_last_comparisons(self.handle)
+
+    def last_kernel_name(self):
+        return self.lib.gkmhip_last_kernel_name(self.handle).decode()
+
+
+def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,
+                kernel=KERNEL_AUTO, symmetric=False):
+    """Whole Gram matrix of `seqs` on one GPU (device memory through torch).
+
+    Returns dict(K=torch fp64 [n,n] (lower triangle + unit diagonal; upper too if symmetric),
+    P=int32 [n,n,d+1] or None, sqnorm=[n], kernel=name, ms=device ms of the gram kernel)."""
+    import torch
+    ctx = GramContext(kernel_type, L, k, d, M, H, gamma, device)
+    try:
+        ctx.set_kernel(kernel)
+        dev = torch.device("cuda", device)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx.set_sequences(seqs, stream)
+            n = len(seqs)
+            G = torch.zeros((n, n), dtype=torch.float64, device=dev)
+            P = torch.zeros((n, n, d + 1), dtype=torch.int32, device=dev) if want_profiles else None
+            sq = torch.zeros(n, dtype=torch.float64, device=dev)
+            ctx.gram_rows(np.arange(n), G.data_ptr(), n, P.data_ptr() if want_profiles else None, n, False, stream)
+            ctx.normalize(G.data_ptr(), n, sq.data_ptr(), symmetric, stream)
+            torch.cuda.synchronize(dev)
+            return dict(K=G, P=P, sqnorm=sq, kernel=ctx.last_kernel_name(), ms=ctx.last_kernel_ms(),
+                        comparisons=ctx.last_comparisons())
+    finally:
+        ctx.close()

@@ -1,0 +1,64 @@
+"""The bit-sliced lane program (gkmqc_amd/csrc/gkm_bitslice.h) run on the CPU through
+bitslice_cpu_probe.so, against the oracle's brute-force profile.  This exercises the same
+templates the HIP kernel instantiates: strided planes, SB tables, the sliding window-sum
+tree, the <= d test, and hit consumption with weights."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+CASES = [(10, 11, 3), (10, 10, 3), (10, 12, 4), (10, 8, 4), (10, 9, 4), (10, 12, 6), (10, 4, 2), (10, 2, 1),
+         (10, 3, 0), (10, 5, 2), (10, 6, 3), (10, 7, 3), (5, 11, 3), (16, 11, 3), (3, 12, 4), (10, 12, 8),
+         (10, 12, 12), (10, 11, 1)]
+
+
+@pytest.fixture(scope="module")
+def libs(built):
+    from oracle import oracle as O
+    probe = ctypes.CDLL(os.path.join(helpers.ROOT, "gkmqc_amd", "csrc", "bitslice_cpu_probe.so"))
+    return O, probe
+
+
+def _oracle_profile(O, t, L, d, A, B):
+    opt = O.make_opt(t, L, L - d, d)
+    P = np.zeros(d + 1, dtype=np.int32)
+    O.lib().gkmo_profile(ctypes.byref(opt), A.ctypes.data_as(ctypes.c_void_p), len(A),
+                         B.ctypes.data_as(ctypes.c_void_p), len(B), P.ctypes.data_as(ctypes.c_void_p))
+    return P
+
+
+def _probe_profile(O, probe, W, t, L, d, A, B):
+    P = np.zeros(d + 1, dtype=np.int32)
+    vp = ctypes.c_void_p
+    if t in (4, 5):
+        wa = O.position_weights(t, len(A) - L + 1)
+        wb = O.position_weights(t, len(B) - L + 1)
+        rc = probe.bsprobe_profile(W, L, d, A.ctypes.data_as(vp), len(A), wa.ctypes.data_as(vp),
+                                   B.ctypes.data_as(vp), len(B), wb.ctypes.data_as(vp), P.ctypes.data_as(vp))
+    else:
+        rc = probe.bsprobe_profile(W, L, d, A.ctypes.data_as(vp), len(A), None, B.ctypes.data_as(vp), len(B), None,
+                                   P.ctypes.data_as(vp))
+    assert rc == 0
+    return P
+
+
+@pytest.mark.parametrize("W,L,d", CASES)
+def test_lane_program_matches_oracle(libs, W, L, d):
+    O, probe = libs
+    rng = np.random.default_rng(1000 * W + 10 * L + d)
+    shapes = [(300, 300), (L, L + 1), (700, 13 if L <= 13 else L), None, None]
+    for trial, shp in enumerate(shapes):
+        la, lb = shp if shp else (int(rng.integers(L, 500)), int(rng.integers(L, 500)))
+        A = rng.integers(0, 4, la).astype(np.uint8)
+        B = rng.integers(0, 4, lb).astype(np.uint8)
+        if trial == 3:
+            B = A.copy()                      # self profile (sqnorm path)
+        if trial == 4:
+            A[:] = 0
+            B[:] = 0                          # poly-A: every window is a hit
+        for t in (2, 4):
+            assert (_oracle_profile(O, t, L, d, A, B) == _probe_profile(O, probe, W, t, L, d, A, B)).all(), \
+                (trial, t, la, lb)

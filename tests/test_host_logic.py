@@ -1,0 +1,149 @@
+"""Host side of the product library (no GPU needed): the C ABI loads and exports what
+include/*.h declares; weights, positional weights and the FASTA reader match the
+reference fixtures; the boundary fails loudly (non-zero, no crash) without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+ROOT = helpers.ROOT
+
+
+@pytest.fixture(scope="module")
+def dev(built):
+    from gkmqc_amd import device
+    device.load()
+    return device
+
+
+def _declared_functions(header):
+    txt = open(os.path.join(ROOT, "include", header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(gkm(?:hip)?_[a-z0-9_]+)\s*\(", txt)))
+
+
+@pytest.mark.parametrize("header", ["gkmkern_pylib.h", "gkm_hip.h"])
+def test_every_declared_symbol_is_exported(dev, header):
+    lib = ctypes.CDLL(dev.lib_path())
+    names = _declared_functions(header)
+    assert len(names) >= 8
+    for name in names:
+        assert hasattr(lib, name), "%s declared in include/%s but not exported" % (name, header)
+
+
+def test_gkmopt_layout_matches_reference(dev):
+    # x86-64 offsets probed from the reference build
+    offs = [getattr(dev.gkmOpt, f).offset for f, _ in dev.gkmOpt._fields_]
+    assert offs == [0, 4, 8, 12, 16, 24, 32, 40, 48, 56, 60]
+    assert ctypes.sizeof(dev.gkmOpt) == 64
+
+
+def test_parameter_check_messages(dev):
+    assert dev.check_parameters(4, 11, 7, 3) is None
+    assert dev.check_parameters(6, 11, 7, 3) == "unknown kernel type"
+    assert dev.check_parameters(-1, 11, 7, 3) == "unknown kernel type"
+    assert dev.check_parameters(2, 1, 1, 0) == "L < 2"
+    assert dev.check_parameters(2, 13, 7, 3) == "L > 12"
+    assert dev.check_parameters(2, 10, 11, 0) == "k > L"
+    assert dev.check_parameters(2, 10, 8, 3) == "d > L - k"
+
+
+def test_mismatch_weights_bit_identical(dev):
+    for (t, L, k, d), ref in helpers.golden_weights().items():
+        got = dev.mismatch_weights(t, L, k)[: d + 1]
+        assert got.tobytes() == ref.tobytes(), (t, L, k, d)
+
+
+def test_position_weights(dev):
+    cases, lens, _ = helpers.quirks_expected()
+    for c in cases:
+        for i, ln in enumerate(lens):
+            n = int(ln) - c["L"] + 1
+            got = dev.position_weights(c["kernel_type"], n, c["M"], c["H"])
+            assert (got == c["wt"][i, :n]).all(), (c["idx"], i)
+
+
+def test_fasta_reader_matches_oracle_and_reference_lengths(dev):
+    from oracle import oracle as O
+    seqs, n_pos, n_invalid, n_trunc = dev.read_problem(helpers.QUIRK_POS, helpers.QUIRK_NEG)
+    oseqs, o_pos, o_invalid, o_trunc = O.read_problem(helpers.QUIRK_POS, helpers.QUIRK_NEG)
+    _, lens, npos = helpers.quirks_expected()
+    assert n_pos == npos == o_pos
+    assert [len(s) for s in seqs] == list(lens)
+    assert all((a == b).all() for a, b in zip(seqs, oseqs))
+    assert (n_invalid, n_trunc) == (o_invalid, o_trunc)
+
+
+def test_fasta_reader_edge_cases(dev, tmp_path):
+    p = tmp_path / "p.fa"
+    n = tmp_path / "n.fa"
+    # text before the first header is ignored; last line without newline; long single line
+    p.write_bytes(b"junk before header\n>a desc\nACGT\n\nacgtn\n>b\n" + b"G" * 3000 + b"\n>c\nTT\r\nGG\r\n>d")
+    n.write_bytes(b">x\nAAAA")
+    seqs, n_pos, n_invalid, n_trunc = dev.read_problem(str(p), str(n))
+    assert n_pos == 4 and len(seqs) == 5
+    assert seqs[0].tolist() == [0, 1, 2, 3, 0, 1, 2, 3, 0]
+    assert len(seqs[1]) == 2047 and n_trunc == 1
+    assert seqs[2].tolist() == [3, 3, 2, 2]
+    assert len(seqs[3]) == 0
+    assert seqs[4].tolist() == [0, 0, 0, 0]
+    assert n_invalid == 1
+    with pytest.raises(dev.GkmError):
+        dev.read_problem(str(tmp_path / "missing.fa"), str(n))
+
+
+def _call_wrapper(dev, opt, nrows=64):
+    kmat = np.full((nrows, nrows), -7.0)
+    rows = (kmat.ctypes.data + np.arange(nrows) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.full(2, -1, dtype=np.int32)
+    rc = dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data)
+    return rc, kmat, sizes
+
+
+def test_boundary_rejects_bad_input_without_touching_output(dev, tmp_path):
+    def opt(**kw):
+        base = dict(kernel_type=4, L=11, k=7, d=3, M=50, H=50.0, gamma=1.0,
+                    posfile=helpers.QUIRK_POS.encode(), negfile=helpers.QUIRK_NEG.encode(), nthreads=1, verbosity=0)
+        base.update(kw)
+        return dev.gkmOpt(**base)
+    for bad in (opt(L=13), opt(d=5), opt(kernel_type=9), opt(verbosity=7),
+                opt(posfile=str(tmp_path / "nope.fa").encode())):
+        rc, kmat, sizes = _call_wrapper(dev, bad)
+        assert rc != 0
+        assert (kmat == -7.0).all() and (sizes == -1).all()
+    empty = tmp_path / "empty.fa"
+    empty.write_bytes(b"")
+    rc, kmat, _ = _call_wrapper(dev, opt(posfile=str(empty).encode()))
+    assert rc != 0 and (kmat == -7.0).all()
+    short = tmp_path / "short.fa"
+    short.write_bytes(b">s\nACGTAC\n")   # shorter than L: undefined in the reference, an error here
+    rc, kmat, _ = _call_wrapper(dev, opt(posfile=str(short).encode()))
+    assert rc != 0 and (kmat == -7.0).all()
+
+
+def test_no_silent_cpu_fallback(dev):
+    """Without a GPU the product must fail loudly; with one it must succeed."""
+    import torch
+    o = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, helpers.QUIRK_POS.encode(), helpers.QUIRK_NEG.encode(), 1, 0)
+    rc, kmat, sizes = _call_wrapper(dev, o)
+    if torch.cuda.is_available():
+        assert rc == 0
+    else:
+        assert rc != 0 and (kmat == -7.0).all()
+        with pytest.raises(dev.GkmError):
+            dev.GramContext(4, 11, 7, 3)
+
+
+def test_product_does_not_reference_the_oracle():
+    """The shipped package must not import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "gkmqc_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", ".cpp")) or f == "Makefile":
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in txt and "gkm_oracle" not in txt and "from oracle" not in txt \
+                    and "import oracle" not in txt and "_ref/" not in txt, os.path.join(dirpath, f)
