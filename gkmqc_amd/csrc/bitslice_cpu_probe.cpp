@@ -13,44 +13,61 @@
 using namespace gkmbs;
 
 template <int W, int L, int D>
-static void run_pair(const uint8_t *A, int lenA, const uint8_t *wtA, const uint8_t *B, int lenB,
-                     const uint8_t *wtB, uint32_t *acc /* [1<<NB] */)
+static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, const uint8_t *wd,
+                     uint32_t *acc /* [1<<NB] */)
 {
     constexpr int NB = planes_for(D);
     constexpr int CAP = segment_capacity(W, L);
     const int nA = lenA - L + 1, nB = lenB - L + 1, T = lenB;
-    for (int k = 0; k < (1 << NB); k++) acc[k] = 0;
+    for (int k = 0; k <= D; k++) acc[k] = 0;
+    (void)NB;
     std::vector<uint32_t> sb[2][3];
     for (int st = 0; st < 2; st++)
         for (int pl = 0; pl < 3; pl++) {
             sb[st][pl].resize((size_t)T + W);
             for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
         }
+    const uint32_t rcpT = mod_magic((uint32_t)T);
+    const int pkw = (T + 15) / 16 + 1;
+    std::vector<uint32_t> colpk((size_t)2 * pkw);
+    for (int st = 0; st < 2; st++)
+        for (int i = 0; i < pkw; i++) colpk[(size_t)st * pkw + i] = strand_pack_word(B, T, st, i);
     for (int s0 = 0; s0 < nA; s0 += CAP) {
-        uint32_t Ahi[W], Alo[W], AV[W];
+        uint32_t Ahi[W], Alo[W], AV[W], rowpk[2 * W + 1];
         for (int w = 0; w < W; w++) {
             Ahi[w] = row_plane_word(A, lenA, s0, w, W, L, 0);
             Alo[w] = row_plane_word(A, lenA, s0, w, W, L, 1);
             AV[w] = row_plane_word(A, lenA, s0, w, W, L, 2);
         }
+        for (int i = 0; i < 2 * W + 1; i++) rowpk[i] = row_pack_word(A, lenA, s0, i);
+        auto rp = [&](int i) { return rowpk[i]; };
+        auto cp = [&](int st, int i) { return colpk[(size_t)st * pkw + i]; };
+        auto wt = [&](int dist) { return (uint32_t)wd[dist]; };
         for (int st = 0; st < 2; st++)
             for (int delta = 0; delta < T; delta++) {
-                Count<NB> cnt[W];
-                window_counts<W, L, NB>(Ahi, Alo, &sb[st][0][(size_t)delta], &sb[st][1][(size_t)delta], cnt);
+                uint32_t hit[W];
+                window_hits<W, L, D>(Ahi, Alo, AV, &sb[st][0][(size_t)delta], &sb[st][1][(size_t)delta],
+                                     &sb[st][2][(size_t)delta], hit);
                 for (int w = 0; w < W; w++) {
-                    const uint32_t h = count_le<NB, D>(cnt[w]) & AV[w] & sb[st][2][(size_t)delta + w];
-                    consume_hits<W, NB>(h, cnt[w].b, delta, w, st, s0, T, nB, wtA ? wtA : nullptr,
-                                        wtA ? wtB : nullptr, acc);
+                    uint32_t h = hit[w];
+                    while (h) {
+                        const int bit = __builtin_ctz(h);
+                        h &= h - 1u;
+                        const HitValue hv = wd ? resolve_hit<W, L, true>(bit, w, delta, st, s0, (uint32_t)T, rcpT, nA / 2, nB, rp, cp, wt)
+                                               : resolve_hit<W, L, false>(bit, w, delta, st, s0, (uint32_t)T, rcpT, nA / 2, nB, rp, cp, wt);
+                        acc[hv.m] += hv.v;
+                    }
                 }
             }
     }
 }
 
 #define CASE(WW, LL, DD) \
-    if (W == WW && L == LL && d == DD) { run_pair<WW, LL, DD>(A, lenA, wtA, B, lenB, wtB, acc); ok = 1; }
+    if (W == WW && L == LL && d == DD) { run_pair<WW, LL, DD>(A, lenA, B, lenB, wd, acc); ok = 1; }
 
-extern "C" int bsprobe_profile(int W, int L, int d, const uint8_t *A, int lenA, const uint8_t *wtA,
-                               const uint8_t *B, int lenB, const uint8_t *wtB, int32_t *P)
+/* wd: distance-indexed positional weight table (NULL = unweighted) */
+extern "C" int bsprobe_profile(int W, int L, int d, const uint8_t *A, int lenA, const uint8_t *B, int lenB,
+                               const uint8_t *wd, int32_t *P)
 {
     uint32_t acc[16] = {0};
     int ok = 0;

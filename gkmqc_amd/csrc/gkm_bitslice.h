@@ -46,133 +46,200 @@ constexpr int planes_for(int d) { return d <= 1 ? 1 : d <= 3 ? 2 : d <= 7 ? 3 : 
  * complete windows of the segment's own starts; the next segment begins here) */
 constexpr int segment_capacity(int W, int L) { return 32 * W - (L - 1); }
 
-template <int NB>
-struct Count {
-    uint32_t b[NB]; /* binary digits of the per-bit-position count */
-    uint32_t ovf;   /* sticky: count exceeded 2^NB - 1 somewhere on the way */
+/* ------------------------------------------------------------------ lop3 */
+/* Any 3-input bitwise function in one full-rate VALU op: gfx950's v_bitop3_b32.  TT is the
+ * truth table f(0xF0, 0xCC, 0xAA).  (v_and_or_b32 / v_or3_b32 issue at HALF rate on MI355X,
+ * v_bitop3_b32 at full rate -- tools/valu_peak.hip -- so every 3-input op below is a lop3.) */
+template <int TT>
+GKM_HD uint32_t lop3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(a, b, c, TT);
+#else
+    uint32_t r = 0u;
+    for (int k = 0; k < 8; k++)
+        if ((TT >> k) & 1) r |= ((k & 4) ? a : ~a) & ((k & 2) ? b : ~b) & ((k & 1) ? c : ~c);
+    return r;
+#endif
+}
+constexpr int TT_XOR3 = 0x96;     /* a ^ b ^ c */
+constexpr int TT_MAJ = 0xE8;      /* majority(a, b, c) */
+constexpr int TT_OR3 = 0xFE;      /* a | b | c */
+constexpr int TT_A_OR_BXC = 0xF6; /* a | (b ^ c) */
+constexpr int TT_NA_B_C = 0x08;   /* ~a & b & c */
+
+constexpr int bitlen(int v)
+{
+    int n = 0;
+    while (v) { n++; v >>= 1; }
+    return n;
+}
+
+/* Bit-sliced count whose value is known (at compile time) to lie in 0..MX.  Only the planes
+ * that can be non-zero exist; `ovf` exists (is meaningful) iff MX does not fit NB planes. */
+template <int NB, int MX>
+struct Cnt {
+    static constexpr int P = bitlen(MX) < NB ? bitlen(MX) : NB;
+    static constexpr bool OV = MX >= (1 << NB);
+    uint32_t b[P > 0 ? P : 1];
+    uint32_t ovf;
 };
 
-template <int NB>
-GKM_HD Count<NB> count_from_bit(uint32_t z)
+template <int PX, int PY, bool CIN>
+constexpr bool carry_into(int i)
 {
-    Count<NB> r;
-    r.b[0] = z;
-#pragma unroll
-    for (int i = 1; i < NB; i++) r.b[i] = 0u;
-    r.ovf = 0u;
-    return r;
+    return i == 0 ? CIN : (((i - 1 < PX) ? 1 : 0) + ((i - 1 < PY) ? 1 : 0) + (carry_into<PX, PY, CIN>(i - 1) ? 1 : 0)) >= 2;
 }
 
-/* ripple-carry add of two bit-sliced counts (+ optional 1-bit carry-in plane).
- * sum = x ^ y ^ c ; carry = majority(x, y, c) = (t & c) | (~t & x) with t = x ^ y
- * (one v_bfi_b32).  Planes known to be zero fold away after full unrolling. */
-template <int NB>
-GKM_HD Count<NB> count_add(const Count<NB> &x, const Count<NB> &y, uint32_t cin = 0u)
+template <int I, int NB, int M1, int M2, bool CIN>
+GKM_HD void add_plane(const Cnt<NB, M1> &x, const Cnt<NB, M2> &y, uint32_t &c, Cnt<NB, M1 + M2 + (CIN ? 1 : 0)> &r)
 {
-    Count<NB> r;
-    uint32_t c = cin;
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        const uint32_t t = x.b[i] ^ y.b[i];
-        r.b[i] = t ^ c;
-        c = (t & c) | (~t & x.b[i]);
-    }
-    r.ovf = x.ovf | y.ovf | c;
-    return r;
-}
-
-/* bit mask of positions whose count is <= D (D compile-time, 0 <= D < 2^NB) */
-template <int NB, int D>
-GKM_HD uint32_t count_le(const Count<NB> &v)
-{
-    uint32_t less = 0u, eq = ~0u;
-#pragma unroll
-    for (int i = NB - 1; i >= 0; i--) {
-        if ((D >> i) & 1) {
-            less |= eq & ~v.b[i];
-            eq &= v.b[i];
+    using X = Cnt<NB, M1>;
+    using Y = Cnt<NB, M2>;
+    using R = Cnt<NB, M1 + M2 + (CIN ? 1 : 0)>;
+    if constexpr (I < R::P) {
+        constexpr bool hx = I < X::P, hy = I < Y::P, hc = carry_into<X::P, Y::P, CIN>(I);
+        constexpr int nin = (hx ? 1 : 0) + (hy ? 1 : 0) + (hc ? 1 : 0);
+        /* the carry out of this plane is wanted by the next plane, or by ovf if this is plane NB-1 */
+        constexpr bool want_c = nin >= 2 && ((I + 1 < R::P) || (I + 1 == NB && R::OV));
+        if constexpr (nin == 3) {
+            const uint32_t xi = x.b[I], yi = y.b[I], ci = c;
+            r.b[I] = lop3<TT_XOR3>(xi, yi, ci);
+            if constexpr (want_c) c = lop3<TT_MAJ>(xi, yi, ci);
+        } else if constexpr (nin == 2) {
+            const uint32_t u = hx ? x.b[I] : y.b[I];
+            const uint32_t v = hc ? c : y.b[I];
+            r.b[I] = u ^ v;
+            if constexpr (want_c) c = u & v;
+        } else if constexpr (nin == 1) {
+            r.b[I] = hx ? x.b[I] : (hy ? y.b[I] : c);
         } else {
-            eq &= ~v.b[i];
+            r.b[I] = 0u;
         }
     }
-    return (less | eq) & ~v.ovf;
 }
 
-struct Parts {
-    int n;
-    int size[4];
-    int off[4];
-};
-constexpr Parts make_parts(int L)
+/* x + y (+ a one-bit carry-in plane): 2 ops per full-adder plane, 2 per half-adder plane */
+template <bool CIN, int NB, int M1, int M2>
+GKM_HD Cnt<NB, M1 + M2 + (CIN ? 1 : 0)> cnt_add(const Cnt<NB, M1> &x, const Cnt<NB, M2> &y, uint32_t cin = 0u)
 {
-    Parts p{};
-    int o = 0;
-    for (int sz = 8; sz >= 1; sz >>= 1)
-        if (L & sz) {
-            p.size[p.n] = sz;
-            p.off[p.n] = o;
-            o += sz;
-            p.n++;
+    using X = Cnt<NB, M1>;
+    using Y = Cnt<NB, M2>;
+    using R = Cnt<NB, M1 + M2 + (CIN ? 1 : 0)>;
+    R r;
+    uint32_t c = cin;
+    add_plane<0, NB, M1, M2, CIN>(x, y, c, r);
+    add_plane<1, NB, M1, M2, CIN>(x, y, c, r);
+    add_plane<2, NB, M1, M2, CIN>(x, y, c, r);
+    add_plane<3, NB, M1, M2, CIN>(x, y, c, r);
+    r.ovf = 0u;
+    if constexpr (R::OV) {
+        /* carry out of plane NB-1 exists iff that plane had >= 2 inputs */
+        constexpr bool hc = R::P == NB && (((NB - 1 < X::P) ? 1 : 0) + ((NB - 1 < Y::P) ? 1 : 0) +
+                                           (carry_into<X::P, Y::P, CIN>(NB - 1) ? 1 : 0)) >= 2;
+        constexpr int terms = (X::OV ? 1 : 0) + (Y::OV ? 1 : 0) + (hc ? 1 : 0);
+        if constexpr (terms == 3) r.ovf = lop3<TT_OR3>(x.ovf, y.ovf, c);
+        else if constexpr (terms == 2) r.ovf = X::OV ? (x.ovf | (Y::OV ? y.ovf : c)) : (y.ovf | c);
+        else if constexpr (terms == 1) r.ovf = X::OV ? x.ovf : (Y::OV ? y.ovf : c);
+    }
+    return r;
+}
+
+/* truth table of [value(b2 b1 b0) > D] for a lop3 over three count planes */
+constexpr int tt_gt3(int D)
+{
+    int tt = 0;
+    for (int k = 0; k < 8; k++)
+        if (k > D) tt |= 1 << k;
+    return tt;
+}
+/* truth table of [ovf | value(b1 b0) > D] with inputs (b1, b0, ovf) */
+constexpr int tt_gt2_or(int D)
+{
+    int tt = 0;
+    for (int k = 0; k < 8; k++)
+        if ((k & 1) || ((k >> 1) > D)) tt |= 1 << k;
+    return tt;
+}
+
+/* mask of positions where the count is NOT <= D (too many mismatches or overflowed) */
+template <int D, int NB, int MX>
+GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
+{
+    using V = Cnt<NB, MX>;
+    if constexpr (MX <= D) {
+        return 0u;
+    } else if constexpr (V::P <= 2) {
+        const uint32_t b1 = V::P > 1 ? v.b[V::P > 1 ? 1 : 0] : 0u, b0 = V::P > 0 ? v.b[0] : 0u;
+        if constexpr (D >= 3) return V::OV ? v.ovf : 0u;
+        else return lop3<tt_gt2_or(D)>(b1, b0, V::OV ? v.ovf : 0u);
+    } else if constexpr (V::P == 3) {
+        if constexpr (D >= 7) return V::OV ? v.ovf : 0u;
+        else {
+            const uint32_t gt = lop3<tt_gt3(D)>(v.b[2], v.b[1], v.b[0]);
+            return V::OV ? (gt | v.ovf) : gt;
         }
-    return p;
+    } else {
+        uint32_t gt;
+        if constexpr (D >= 15) gt = 0u;
+        else if constexpr (D >= 8) gt = v.b[3] & lop3<tt_gt3(D - 8)>(v.b[2], v.b[1], v.b[0]);
+        else gt = v.b[3] | lop3<tt_gt3(D)>(v.b[2], v.b[1], v.b[0]);
+        return V::OV ? (gt | v.ovf) : gt;
+    }
 }
 
 /*
- * One shift `delta` of one column strand against one row segment.
- *   Ahi/Alo : the segment's planes, W words each (per lane)
- *   Bhi/Blo : SB words x = delta .. delta+W-1 of the column strand (uniform)
- * Produces for w in [0,W): cnt[w] = per-bit mismatch count of the L-window starting at
- * segment base b*W + w, saturating (ovf) above 2^NB-1.
+ * One cyclic shift of one column strand against one row segment.
+ *   Ahi/Alo/AV : the segment's planes, W words each (per lane)
+ *   Bhi/Blo/Bv : SB words x = delta .. delta+W-1 of the column strand (wave-uniform)
+ * For w in [0,W): hit[w] = windows (bit b <-> segment base b*W + w) with <= D mismatches
+ * whose start is valid on both sides.  The exact count of a hit is recomputed from the
+ * packed l-mers when the hit is consumed (cheaper than carrying the count planes along).
  */
-template <int W, int L, int NB>
-GKM_HD void window_counts(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t *Bhi,
-                          const uint32_t *Blo, Count<NB> *cnt)
+template <int W, int L, int D>
+GKM_HD void window_hits(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t *AV, const uint32_t *Bhi,
+                        const uint32_t *Blo, const uint32_t *Bv, uint32_t *hit)
 {
+    constexpr int NB = planes_for(D);
     constexpr int NX = W + L - 1;
     uint32_t Z[NX];
 #pragma unroll
-    for (int w = 0; w < W; w++) Z[w] = (Ahi[w] ^ Bhi[w]) | (Alo[w] ^ Blo[w]);
+    for (int w = 0; w < W; w++) Z[w] = lop3<TT_A_OR_BXC>(Ahi[w] ^ Bhi[w], Alo[w], Blo[w]);
 #pragma unroll
     for (int x = W; x < NX; x++) Z[x] = Z[x - W] >> 1; /* word x == word x-W one bit up */
 
-    /* sliding power-of-two window sums; unused levels are dead code */
-    Count<NB> s1[NX], s2[NX], s4[NX], s8[NX];
+    /* sliding power-of-two window sums; levels L does not use are dead code */
+    Cnt<NB, 1> s1[NX];
+    Cnt<NB, 2> s2[NX];
+    Cnt<NB, 4> s4[NX];
+    Cnt<NB, 8> s8[NX];
 #pragma unroll
-    for (int x = 0; x < NX; x++) s1[x] = count_from_bit<NB>(Z[x]);
+    for (int x = 0; x < NX; x++) { s1[x].b[0] = Z[x]; s1[x].ovf = 0u; }
 #pragma unroll
-    for (int x = 0; x + 1 < NX; x++) s2[x] = count_add<NB>(s1[x], s1[x + 1]);
+    for (int x = 0; x + 1 < NX; x++) s2[x] = cnt_add<false>(s1[x], s1[x + 1]);
 #pragma unroll
-    for (int x = 0; x + 3 < NX; x++) s4[x] = count_add<NB>(s2[x], s2[x + 2]);
+    for (int x = 0; x + 3 < NX; x++) s4[x] = cnt_add<false>(s2[x], s2[x + 2]);
 #pragma unroll
-    for (int x = 0; x + 7 < NX; x++) s8[x] = count_add<NB>(s4[x], s4[x + 4]);
+    for (int x = 0; x + 7 < NX; x++) s8[x] = cnt_add<false>(s4[x], s4[x + 4]);
 
-    constexpr Parts P = make_parts(L);
 #pragma unroll
     for (int w = 0; w < W; w++) {
-        /* L = 8*e8 + 4*e4 + 2*e2 + e1: chain the blocks left to right; a trailing
-         * single base rides as the carry-in of the last two-operand add */
-        Count<NB> part[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            part[k] = count_from_bit<NB>(0u);
-            if (k < P.n) {
-                const int x = w + P.off[k];
-                if (P.size[k] == 8) part[k] = s8[x];
-                else if (P.size[k] == 4) part[k] = s4[x];
-                else if (P.size[k] == 2) part[k] = s2[x];
-                else part[k] = s1[x];
-            }
-        }
-        Count<NB> acc = part[0];
-        if (P.n == 2) {
-            acc = count_add<NB>(acc, part[1]);
-        } else if (P.n == 3) {
-            if (P.size[2] == 1) acc = count_add<NB>(acc, part[1], Z[w + P.off[2]]);
-            else acc = count_add<NB>(count_add<NB>(acc, part[1]), part[2]);
-        } else if (P.n == 4) {
-            acc = count_add<NB>(count_add<NB>(acc, part[1]), part[2], Z[w + P.off[3]]);
-        }
-        cnt[w] = acc;
+        /* L = 8*e8 + 4*e4 + 2*e2 + e1: add the blocks left to right; a trailing single base
+         * rides as the carry-in of the last two-operand add */
+        Cnt<NB, L> tot;
+        if constexpr (L == 12) tot = cnt_add<false>(s8[w], s4[w + 8]);
+        else if constexpr (L == 11) tot = cnt_add<true>(s8[w], s2[w + 8], Z[w + 10]);
+        else if constexpr (L == 10) tot = cnt_add<false>(s8[w], s2[w + 8]);
+        else if constexpr (L == 9) tot = cnt_add<false>(s8[w], s1[w + 8]);
+        else if constexpr (L == 8) tot = s8[w];
+        else if constexpr (L == 7) tot = cnt_add<true>(s4[w], s2[w + 4], Z[w + 6]);
+        else if constexpr (L == 6) tot = cnt_add<false>(s4[w], s2[w + 4]);
+        else if constexpr (L == 5) tot = cnt_add<false>(s4[w], s1[w + 4]);
+        else if constexpr (L == 4) tot = s4[w];
+        else if constexpr (L == 3) tot = cnt_add<false>(s2[w], s1[w + 2]);
+        else tot = s2[w];
+        static_assert(L >= 2 && L <= 12, "L out of range");
+        hit[w] = lop3<TT_NA_B_C>(cnt_exceeds<D>(tot), AV[w], Bv[w]);
     }
 }
 
@@ -219,37 +286,111 @@ GKM_HD uint32_t sb_word(const uint8_t *codes, int T, int strand, int x, int W, i
 }
 
 /* ------------------------------------------------------------------- hits */
-/* Consume the hit bits of one word: for each set bit b of h the l-mer pair
- *   row window start  p = s0 + b*W + w           (weight wtA[p])
- *   column l-mer      q = (b*W + w + delta) mod T on `strand`
- *                     (weight wtB[q] forward, wtB[nB-1-q] reverse: libgkm.c:924)
- * has m = count bits (c[0..NB-1] at bit b) mismatches, m <= d.  acc[m] += wa*wb in
- * wrapping 32-bit arithmetic (the reference's int, libgkm.c:338).
- * wtA/wtB may be NULL for unweighted kernels (all weights 1). */
-template <int W, int NB>
-GKM_HD void consume_hits(uint32_t h, const uint32_t *c, int delta, int w, int strand, int s0, int T,
-                         int nB, const uint8_t *wtA, const uint8_t *wtB, uint32_t *acc)
+/* exact x mod T for x < 2^32 / T, with rcp = ceil(2^32 / T) (T >= 2) */
+GKM_HD uint32_t mod_magic(uint32_t T) { return 0xFFFFFFFFu / T + 1u; }
+GKM_HD uint32_t mod_small(uint32_t x, uint32_t T, uint32_t rcp)
 {
-    while (h) {
-        const int b = __builtin_ctz(h);
-        h &= h - 1u;
-        int m = 0;
-#pragma unroll
-        for (int i = 0; i < NB; i++) m |= (int)((c[i] >> b) & 1u) << i;
-        const int i0 = b * W + w;
-        const int q = (i0 + delta) % T;
-        uint32_t v = 1u;
-        if (wtA) v = (uint32_t)wtA[s0 + i0] * (uint32_t)wtB[strand ? (nB - 1 - q) : q];
-#pragma unroll
-        for (int k = 0; k < (1 << NB); k++) acc[k] += (k == m) ? v : 0u;
-    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return x - __umulhi(x, rcp) * T;
+#else
+    return x - (uint32_t)(((uint64_t)x * rcp) >> 32) * T;
+#endif
 }
 
-/* queue entry meta word: delta | w << 11 | strand << 17 */
+/* Positional weights as a function of the distance to the sequence's centre l-mer:
+ * w(n, p) = wd[|n/2 - p|] (libgkm.c:912-925 depends on n and p only through that
+ * distance), so ONE small table serves every sequence length. */
+GKM_HD uint32_t dist_weight(const uint8_t *wd, int center, int p)
+{
+    const int dd = center - p;
+    return wd[dd < 0 ? -dd : dd];
+}
+
+/* 2-bit packed bases, 16 per word, base i at bits 2*(i%16)..+1 of word i/16 */
+GKM_HD uint32_t row_pack_word(const uint8_t *codes, int len, int s0, int widx)
+{
+    uint32_t v = 0u;
+    for (int k = 0; k < 16; k++) {
+        const int pos = s0 + widx * 16 + k;
+        if (pos < len) v |= (uint32_t)codes[pos] << (2 * k);
+    }
+    return v;
+}
+GKM_HD uint32_t strand_pack_word(const uint8_t *codes, int T, int strand, int widx)
+{
+    uint32_t v = 0u;
+    for (int k = 0; k < 16; k++) {
+        const int q = widx * 16 + k;
+        if (q < T) v |= (uint32_t)(strand ? (3u - codes[T - 1 - q]) : codes[q]) << (2 * k);
+    }
+    return v;
+}
+/* the L bases starting at base `pos`, given the two packed words that hold them */
+GKM_HD uint32_t lmer_bits(uint32_t w0, uint32_t w1, int pos, int L)
+{
+    const int sh = (pos & 15) * 2;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t v = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)sh);
+#else
+    const uint32_t v = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
+#endif
+    return v & ((1u << (2 * L)) - 1u);
+}
+GKM_HD int lmer_mismatch(uint32_t x, uint32_t y)
+{
+    uint32_t t = x ^ y;
+    t = (t | (t >> 1)) & 0x55555555u;
+    return __builtin_popcount(t);
+}
+
+/* Resolve one hit: bit b of the hit word of (delta, w, strand) against a row segment.
+ *   row window start  p = s0 + b*W + w           (weight wd[|cA - p|])
+ *   column l-mer      q = (b*W + w + delta) mod T on `strand`
+ *                     (weight wd[|cB - q|] forward, wd[|cB - (nB-1-q)|] reverse: libgkm.c:924)
+ * Returns m = Hamming distance of the two l-mers (<= d for a true hit) and v = wa*wb, the
+ * amount the reference adds to mmprofile[m] (libgkm.c:338).
+ *   rowpk(i)         packed word i of the row segment
+ *   colpk(strand, i) packed word i of the column strand
+ *   wt(dist)         positional weight at distance dist from the centre l-mer */
+struct HitValue {
+    int m;
+    uint32_t v;
+};
+template <int W, int L, bool WEIGHTED, class RowPk, class ColPk, class Wt>
+GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, int s0, uint32_t T, uint32_t rcpT, int cA, int nB,
+                            RowPk rowpk, ColPk colpk, Wt wt)
+{
+    HitValue r;
+    const int i0 = b * W + w;
+    const uint32_t la = lmer_bits(rowpk(i0 >> 4), rowpk((i0 >> 4) + 1), i0, L);
+    uint32_t x = (uint32_t)(i0 + delta);
+    int q;
+    if (T >= (uint32_t)(32 * W)) { /* x < 2T: one conditional subtraction (uniform test) */
+        const uint32_t y = x - T;
+        q = (int)(y < x ? y : x);
+    } else {
+        q = (int)mod_small(x, T, rcpT);
+    }
+    const uint32_t lb = lmer_bits(colpk(strand, q >> 4), colpk(strand, (q >> 4) + 1), q, L);
+    r.m = lmer_mismatch(la, lb);
+    r.v = 1u;
+    if (WEIGHTED) {
+        const int da = cA - (s0 + i0), db = nB / 2 - (strand ? (nB - 1 - q) : q);
+        r.v = wt(da < 0 ? -da : da) * wt(db < 0 ? -db : db);
+    }
+    return r;
+}
+
+/* hit record: w (6 bits) | delta << 6 (11) | strand << 17 | source lane << 18 (6) | bit << 24 (5) */
 GKM_HD uint32_t pack_meta(int delta, int w, int strand)
 {
-    return (uint32_t)delta | ((uint32_t)w << 11) | ((uint32_t)strand << 17);
+    return (uint32_t)w | ((uint32_t)delta << 6) | ((uint32_t)strand << 17);
 }
+GKM_HD int rec_w(uint32_t r) { return (int)(r & 63u); }
+GKM_HD int rec_delta(uint32_t r) { return (int)((r >> 6) & 2047u); }
+GKM_HD int rec_strand(uint32_t r) { return (int)((r >> 17) & 1u); }
+GKM_HD int rec_lane(uint32_t r) { return (int)((r >> 18) & 63u); }
+GKM_HD int rec_bit(uint32_t r) { return (int)(r >> 24); }
 
 } /* namespace gkmbs */
 #endif

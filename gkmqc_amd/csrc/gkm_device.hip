@@ -22,6 +22,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/gkm_hip.h"
@@ -91,15 +92,16 @@ struct gkmhip_ctx {
     std::vector<int> h_len;
     std::vector<int64_t> h_lmoff;
     std::vector<double> h_cum_n; /* prefix sums of n_j = len_j - L + 1 */
-    DevBuf<uint8_t> codes, wt;
+    DevBuf<uint8_t> codes, wd; /* wd: distance-indexed positional weights */
+    int wd_len = 0;
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
-    DevBuf<uint32_t> lmf, lmr, sb;
-    int sb_xw = 0, sb_W = 0;
+    DevBuf<uint32_t> lmf, lmr, sb, pk; /* pk: 2-bit packed strands, 16 bases per word */
+    int sb_xw = 0, sb_W = 0, pkw = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch */
     DevBuf<int> rows, seg_seq, seg_s0, seg_slot, tile_amax;
-    DevBuf<uint32_t> rowplanes;
+    DevBuf<uint32_t> rowplanes, rowpk;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -146,8 +148,9 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
-    ctx->codes.release(); ctx->wt.release(); ctx->off.release(); ctx->lmoff.release();
-    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
+    ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release(); ctx->pk.release();
+    ctx->rowpk.release();
     ctx->rows.release(); ctx->seg_seq.release(); ctx->seg_s0.release(); ctx->seg_slot.release();
     ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -187,35 +190,44 @@ __global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *_
     }
 }
 
-/* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
+/* grid (sequence*2+strand, plane 0..3); threads over words.  planes 0..2: the strand's SB
+ * table (strided bit planes); plane 3: the strand as 2-bit packed bases (pk, pkw words) */
 __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
-                           int L, int xw, uint32_t *__restrict__ sb)
+                           int L, int xw, uint32_t *__restrict__ sb, int pkw, uint32_t *__restrict__ pk)
 {
     const int e = blockIdx.x, plane = blockIdx.y;
     const int s = e >> 1, strand = e & 1;
     const uint8_t *seq = codes + off[s];
     const int T = (int)(off[s + 1] - off[s]);
+    if (plane == 3) {
+        for (int i = threadIdx.x; i < pkw; i += blockDim.x)
+            pk[(size_t)e * pkw + i] = gkmbs::strand_pack_word(seq, T, strand, i);
+        return;
+    }
     uint32_t *dst = sb + ((size_t)e * 3 + plane) * xw;
     for (int x = threadIdx.x; x < xw; x += blockDim.x)
         dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
 }
 
-/* grid (tile, plane); 64 threads = the tile's lanes; layout [tile][plane][w][lane] */
+/* grid (tile, plane 0..3); 64 threads = the tile's lanes.  planes 0..2: bit planes,
+ * layout [tile][plane][w][lane]; plane 3: packed bases of the segment, [tile][2W+1][lane] */
 __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
                                   const int *__restrict__ seg_seq, const int *__restrict__ seg_s0, int W,
-                                  int L, uint32_t *__restrict__ planes)
+                                  int L, uint32_t *__restrict__ planes, uint32_t *__restrict__ rowpk)
 {
     const int tile = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
     const int s = seg_seq[tile * 64 + lane];
     const int s0 = seg_s0[tile * 64 + lane];
-    for (int w = 0; w < W; w++) {
-        uint32_t v = 0u;
-        if (s >= 0) {
-            const int len = (int)(off[s + 1] - off[s]);
-            v = gkmbs::row_plane_word(codes + off[s], len, s0, w, W, L, plane);
-        }
-        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] = v;
+    const int len = s >= 0 ? (int)(off[s + 1] - off[s]) : 0;
+    const uint8_t *seq = codes + (s >= 0 ? off[s] : 0);
+    if (plane == 3) {
+        for (int i = 0; i < 2 * W + 1; i++)
+            rowpk[((size_t)tile * (2 * W + 1) + i) * 64 + lane] = s >= 0 ? gkmbs::row_pack_word(seq, len, s0, i) : 0u;
+        return;
     }
+    for (int w = 0; w < W; w++)
+        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] =
+            s >= 0 ? gkmbs::row_plane_word(seq, len, s0, w, W, L, plane) : 0u;
 }
 
 /* ------------------------------------------------------------ hot kernels */
@@ -228,21 +240,39 @@ struct GramOut {
 };
 
 struct BsArgs {
-    const uint32_t *rowplanes;
+    const uint32_t *rowplanes, *rowpk, *pk;
+    int pkw;
     const int *seg_seq, *seg_s0, *seg_slot, *tile_amax;
     const uint32_t *sb;
     int xw;
     const int *len;
-    const int64_t *lmoff;
-    const uint8_t *wt;
+    const uint8_t *wd; /* distance-indexed positional weights, wd_len bytes */
+    int wd_len;
     double c[GKM_MAXD1];
     GramOut out;
     int cj, maxseg;
 };
 
+constexpr int WD_LDS = 1024; /* >= max |n/2 - p| + 1 for n <= 2047 */
+
 typedef const uint32_t __attribute__((address_space(4))) * sgpr_words;
 
-constexpr int BS_CAP = 16; /* hit-queue entries per lane */
+/* wave64 inclusive prefix sum on the DPP network (no LDS round trips): four row_shr steps
+ * scan each row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across */
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); /* row_bcast:15 -> rows 1,3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2,3 */
+    return x;
+}
+
+constexpr int BS_CAP = 16;     /* hit-queue entries per lane */
+constexpr int BS_SCAP = 384;    /* wave-wide compacted hit words per drain */
+constexpr int BS_PKW_MAX = 130; /* packed words per strand: ceil(2047/16) + 1 */
 constexpr int BS_DU = 5;   /* shifts per SB register refill */
 
 /*
@@ -252,14 +282,23 @@ constexpr int BS_DU = 5;   /* shifts per SB register refill */
  * Hit words are parked in a per-lane LDS queue and turned into weighted profile counts
  * in batches, so the hot loop has no data-dependent control flow besides the push.
  */
-template <int W, int L, int D, bool WEIGHTED>
+template <int W, int L, int D, bool WEIGHTED, int VARIANT = 0>
 __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
 {
+    /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
+     * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
+     * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
     using namespace gkmbs;
-    constexpr int NB = planes_for(D);
-    constexpr int NACC = 1 << NB;
-    constexpr int NF = NB + 2; /* queue fields: h, count planes, meta */
-    __shared__ uint32_t q[NF * BS_CAP * 64];
+    __shared__ uint32_t q_h[BS_CAP * 64];        /* per-lane hit queue: hit word ...              */
+    __shared__ uint32_t q_meta[BS_CAP * 64];     /* ... and where it came from (w, delta, strand) */
+    __shared__ uint32_t s_h[BS_SCAP];            /* wave-wide compacted list of hit words ...     */
+    __shared__ uint32_t s_meta[BS_SCAP];         /* ... with origin incl. the source lane         */
+    __shared__ uint32_t rowpk[(2 * W + 1) * 64]; /* every lane's segment, 2-bit packed            */
+    __shared__ uint32_t rowinfo[64];             /* s0 | centre << 12 of every lane               */
+    __shared__ uint32_t colpk[2 * BS_PKW_MAX];   /* both strands of the current column sequence   */
+    __shared__ uint32_t accl[(D + 1) * 64];      /* mismatch profile accumulators [m][lane]       */
+    __shared__ uint32_t wdl32[WEIGHTED ? WD_LDS / 4 : 1];
+    const uint8_t *wdl = (const uint8_t *)wdl32;
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
@@ -267,6 +306,14 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int j0 = blockIdx.x * A.cj;
     const int j1 = min(j0 + A.cj, amax + 1);
     if (j0 >= j1) return;
+
+    /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
+    if (WEIGHTED) {
+        const uint32_t *src = (const uint32_t *)A.wd;
+        for (int i = lane; i < WD_LDS / 4; i += 64) wdl32[i] = src[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 2 * W + 1; i++) rowpk[i * 64 + lane] = A.rowpk[((size_t)tile * (2 * W + 1) + i) * 64 + lane];
 
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
@@ -278,27 +325,94 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int myseq = A.seg_seq[tile * 64 + lane];
     const int s0 = A.seg_s0[tile * 64 + lane];
     const int slot = A.seg_slot[tile * 64 + lane];
-    const uint8_t *wtA = WEIGHTED ? (A.wt + (myseq >= 0 ? A.lmoff[myseq] : 0)) : nullptr;
+    const int cA = myseq >= 0 ? (A.len[myseq] - L + 1) / 2 : 0; /* centre l-mer, libgkm.c:912 */
+    rowinfo[lane] = (uint32_t)s0 | ((uint32_t)cA << 12);
+    const uint32_t lane_tag = (uint32_t)lane << 18;
+
+    auto wt_at = [&](int dist) { return (uint32_t)wdl[dist]; };
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
         const int nB = T - L + 1;
-        const uint8_t *wtB = WEIGHTED ? (A.wt + A.lmoff[j]) : nullptr;
-        uint32_t acc[NACC];
+        const uint32_t rcpT = mod_magic((uint32_t)T);
+        const int pkw = A.pkw;
+        for (int i = lane; i < 2 * pkw; i += 64) colpk[i] = A.pk[(size_t)(j * 2) * pkw + i];
+        auto col_word = [&](int strand, int i) { return colpk[strand * pkw + i]; };
 #pragma unroll
-        for (int k = 0; k < NACC; k++) acc[k] = 0u;
+        for (int k = 0; k <= D; k++) accl[k * 64 + lane] = 0u;
         int qn = 0;
 
+        /* one hit record -> accl[m][source lane] += wa * wb */
+        auto resolve = [&](uint32_t rec) {
+            const int r = rec_lane(rec);
+            const uint32_t info = rowinfo[r];
+            auto row_word = [&](int i) { return rowpk[i * 64 + r]; };
+            const HitValue hv = resolve_hit<W, L, WEIGHTED>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec),
+                                                            (int)(info & 4095u), (uint32_t)T, rcpT, (int)(info >> 12), nB,
+                                                            row_word, col_word, wt_at);
+            atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
+        };
+
+        /* Compact the per-lane queues of hit words into one wave-wide list (prefix sum of the
+         * queue lengths over the lanes, on DPP), then resolve the list 2 x 64 words at a time with
+         * every lane busy.  A word with more than one hit bit has its remaining bits appended to
+         * the list again.  If the list would not fit (dense, repeat-like input) each lane
+         * resolves its own queue instead: slower, same result. */
         auto drain = [&]() {
-            for (int e = 0; __any(e < qn); e++) {
-                if (e < qn) {
-                    const uint32_t h = q[(0 * BS_CAP + e) * 64 + lane];
-                    uint32_t cb[NB];
+            const int incl = wave_inclusive_scan(qn);
+            int total = __builtin_amdgcn_readlane(incl, 63);
+            if (total <= BS_SCAP - 128) {
+                int pos = incl - qn;
+                for (int e = 0; __any(e < qn); e++) {
+                    if (e < qn) {
+                        s_h[pos] = q_h[e * 64 + lane];
+                        s_meta[pos] = q_meta[e * 64 + lane] | lane_tag;
+                        pos++;
+                    }
+                }
+                for (int i0 = 0; i0 < total;) {
+                    /* this trip covers the words present now; re-appended ones land at >= lim */
+                    const int lim = min(total, i0 + 128);
+                    uint32_t left[2], meta[2];
 #pragma unroll
-                    for (int i = 0; i < NB; i++) cb[i] = q[((1 + i) * BS_CAP + e) * 64 + lane];
-                    const uint32_t meta = q[((NB + 1) * BS_CAP + e) * 64 + lane];
-                    consume_hits<W, NB>(h, cb, (int)(meta & 2047u), (int)((meta >> 11) & 63u),
-                                        (int)((meta >> 17) & 1u), s0, T, nB, wtA, wtB, acc);
+                    for (int k = 0; k < 2; k++) {
+                        const int idx = i0 + k * 64 + lane;
+                        const uint32_t h = (idx < lim) ? s_h[idx] : 0u;
+                        meta[k] = s_meta[min(idx, BS_SCAP - 1)];
+                        if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
+                        left[k] = h & (h - 1u);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const unsigned long long more = __ballot(left[k] != 0u);
+                        if (more) { /* re-append what is left of multi-hit words (rare per lane) */
+                            const int at = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                            if (left[k] != 0u && at < BS_SCAP) {
+                                s_h[at] = left[k];
+                                s_meta[at] = meta[k];
+                            } else if (left[k] != 0u) { /* no room: finish this word here */
+                                uint32_t h = left[k];
+                                while (h) {
+                                    resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
+                                    h &= h - 1u;
+                                }
+                            }
+                            total = min(total + (int)__popcll(more), BS_SCAP);
+                        }
+                    }
+                    i0 = lim;
+                }
+            } else {
+                for (int e = 0; __any(e < qn); e++) {
+                    if (e < qn) {
+                        uint32_t h = q_h[e * 64 + lane];
+                        const uint32_t base = q_meta[e * 64 + lane] | lane_tag;
+                        while (h) {
+                            resolve(base | ((uint32_t)__builtin_ctz(h) << 24));
+                            h &= h - 1u;
+                        }
+                    }
                 }
             }
             qn = 0;
@@ -307,9 +421,10 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
         for (int strand = 0; strand < 2; strand++) {
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
-            const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 3) * A.xw);
-            const sgpr_words sbl = sbh + A.xw;
-            const sgpr_words sbv = sbl + A.xw;
+            typedef typename std::conditional<(VARIANT & 4) != 0, const uint32_t *, sgpr_words>::type sb_ptr;
+            const sb_ptr sbh = (sb_ptr)(A.sb + ((size_t)(j * 2 + strand) * 3) * A.xw);
+            const sb_ptr sbl = sbh + A.xw;
+            const sb_ptr sbv = sbl + A.xw;
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1], bv[BS_DU + W - 1];
 #pragma unroll
@@ -321,36 +436,43 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
 #pragma unroll
                 for (int u = 0; u < BS_DU; u++) {
                     if (d0 + u < T) {
-                        Count<NB> cnt[W];
-                        window_counts<W, L, NB>(Ahi, Alo, bh + u, bl + u, cnt);
+                        uint32_t hit[W];
+                        window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, bv + u, hit);
 #pragma unroll
                         for (int w = 0; w < W; w++) {
-                            const uint32_t h = count_le<NB, D>(cnt[w]) & AV[w] & bv[u + w];
-                            if (h) {
-                                q[(0 * BS_CAP + qn) * 64 + lane] = h;
-#pragma unroll
-                                for (int i = 0; i < NB; i++) q[((1 + i) * BS_CAP + qn) * 64 + lane] = cnt[w].b[i];
-                                q[((NB + 1) * BS_CAP + qn) * 64 + lane] = pack_meta(d0 + u, w, strand);
-                                qn++;
+                            const uint32_t h = hit[w];
+                            if ((VARIANT & 3) == 1) {
+                                accl[lane] += __popc(h);
+                            } else {
+                                /* branch-free push: every lane stores at its own tail, only lanes
+                                 * with a hit advance (a slot without hit is simply overwritten) */
+                                q_h[qn * 64 + lane] = h;
+                                q_meta[qn * 64 + lane] = pack_meta(d0 + u, w, strand);
+                                qn += (h != 0u) ? 1 : 0;
                             }
                         }
-                        if (__any(qn > BS_CAP - W)) drain();
+                        if ((VARIANT & 3) == 2) { if (__any(qn > BS_CAP - W)) qn = 0; }
+                        else if (__any(qn > BS_CAP - W)) drain();
                     }
                 }
             }
         }
         drain();
 
+        uint32_t acc[D + 1];
+#pragma unroll
+        for (int k = 0; k <= D; k++) acc[k] = accl[k * 64 + lane];
+
         /* a sequence longer than one segment occupies consecutive lanes: fold them */
         if (A.maxseg > 1) {
-            uint32_t own[NACC];
+            uint32_t own[D + 1];
 #pragma unroll
-            for (int k = 0; k < NACC; k++) own[k] = acc[k];
+            for (int k = 0; k <= D; k++) own[k] = acc[k];
             for (int s = 1; s < A.maxseg; s++) {
                 const int other = __shfl_down(myseq, s);
                 const bool same = (lane + s < 64) && (other == myseq) && (myseq >= 0);
 #pragma unroll
-                for (int k = 0; k < NACC; k++) {
+                for (int k = 0; k <= D; k++) {
                     const uint32_t t = __shfl_down(own[k], s);
                     if (same) acc[k] += t;
                 }
@@ -378,7 +500,7 @@ struct DirectArgs {
     const int *len;
     const int64_t *lmoff;
     const uint32_t *lmf, *lmr;
-    const uint8_t *wt;
+    const uint8_t *wd;
     double c[GKM_MAXD1];
     GramOut out;
     int cj, L, d;
@@ -418,12 +540,12 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
             for (int r = 0; r < R; r++) {
                 const bool ok = (p0 + r) < na;
                 u[r] = ok ? A.lmf[offa + p0 + r] : 0u;
-                wu[r] = ok ? (WEIGHTED ? (uint32_t)A.wt[offa + p0 + r] : 1u) : 0u; /* padding adds 0 */
+                wu[r] = ok ? (WEIGHTED ? gkmbs::dist_weight(A.wd, na / 2, p0 + r) : 1u) : 0u; /* padding adds 0 */
             }
             for (int qi = 0; qi < nj; qi++) {
                 const uint32_t xf = A.lmf[offj + qi], xr = A.lmr[offj + qi];
-                const uint32_t wf = WEIGHTED ? (uint32_t)A.wt[offj + qi] : 1u;
-                const uint32_t wr = WEIGHTED ? (uint32_t)A.wt[offj + nj - 1 - qi] : 1u; /* libgkm.c:924 */
+                const uint32_t wf = WEIGHTED ? gkmbs::dist_weight(A.wd, nj / 2, qi) : 1u;
+                const uint32_t wr = WEIGHTED ? gkmbs::dist_weight(A.wd, nj / 2, nj - 1 - qi) : 1u; /* libgkm.c:924 */
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     uint32_t t = u[r] ^ xf;
@@ -476,16 +598,15 @@ __global__ void k_normalize(double *__restrict__ G, int64_t ld, int n, const dou
 
 /* ---------------------------------------------------------- host: upload */
 extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
-                                    const uint8_t *wt, const int64_t *wt_offsets, int weighted,
-                                    void *stream_)
+                                    const uint8_t *wdist, int wdist_len, void *stream_)
 {
     if (!ctx || n <= 0 || !codes || !offsets) return set_err_msg("gkmhip_set_sequences: bad arguments", 2);
-    if (weighted && (!wt || !wt_offsets)) return set_err_msg("weighted kernel needs weights", 2);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(ctx->device));
     const int L = ctx->L;
+    const int weighted = (wdist != nullptr && wdist_len > 0) ? 1 : 0;
     ctx->n = n;
-    ctx->weighted = weighted ? 1 : 0;
+    ctx->weighted = weighted;
     ctx->h_len.resize((size_t)n);
     ctx->h_lmoff.resize((size_t)n + 1);
     ctx->h_cum_n.resize((size_t)n + 1);
@@ -500,24 +621,21 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
         ctx->h_lmoff[(size_t)i + 1] = ctx->h_lmoff[(size_t)i] + (len - L + 1);
         ctx->h_cum_n[(size_t)i + 1] = ctx->h_cum_n[(size_t)i] + (double)(len - L + 1);
         ctx->maxlen = std::max(ctx->maxlen, (int)len);
-        if (weighted && wt_offsets[i + 1] - wt_offsets[i] != len - L + 1)
-            return set_err_msg("weight table does not match sequence lengths", 3);
     }
-    const size_t total = (size_t)offsets[n], total_lm = (size_t)ctx->h_lmoff[(size_t)n];
+    if (weighted && (wdist_len <= (ctx->maxlen - L + 1) / 2 || wdist_len > WD_LDS))
+        return set_err_msg("distance weight table must cover 0..max(n)/2 and hold at most 1024 entries", 3);
+    const size_t total = (size_t)offsets[n];
     if (ctx->codes.ensure(total) || ctx->off.ensure((size_t)n + 1) || ctx->lmoff.ensure((size_t)n + 1) ||
-        ctx->len.ensure((size_t)n) || ctx->wt.ensure(total_lm))
+        ctx->len.ensure((size_t)n) || ctx->wd.ensure(WD_LDS))
         return 4;
     HIPCHK(hipMemcpyAsync(ctx->codes.p, codes, total, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ctx->off.p, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ctx->lmoff.p, ctx->h_lmoff.data(), ((size_t)n + 1) * sizeof(int64_t),
                           hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ctx->len.p, ctx->h_len.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
-    if (weighted) {
-        if (wt_offsets[0] != 0) return set_err_msg("wt_offsets[0] must be 0", 3);
-        HIPCHK(hipMemcpyAsync(ctx->wt.p, wt, total_lm, hipMemcpyHostToDevice, stream));
-    } else {
-        HIPCHK(hipMemsetAsync(ctx->wt.p, 1, total_lm, stream));
-    }
+    HIPCHK(hipMemsetAsync(ctx->wd.p, 0, WD_LDS, stream));
+    if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
+    ctx->wd_len = weighted ? wdist_len : 0;
     ctx->have_lmers = false;
     ctx->have_sb = false;
     return 0;
@@ -539,9 +657,11 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 {
     if (ctx->have_sb && ctx->sb_W == W) return 0;
     const int xw = ((ctx->maxlen + W + BS_DU + 15) / 16) * 16;
-    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw)) return 4;
-    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 3), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
-                       W, ctx->L, xw, ctx->sb.p);
+    const int pkw = (ctx->maxlen + 15) / 16 + 1;
+    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw) || ctx->pk.ensure((size_t)ctx->n * 2 * (size_t)pkw)) return 4;
+    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 4), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
+                       W, ctx->L, xw, ctx->sb.p, pkw, ctx->pk.p);
+    ctx->pkw = pkw;
     HIPCHK(hipGetLastError());
     ctx->sb_xw = xw;
     ctx->sb_W = W;
@@ -557,6 +677,14 @@ static bs_kernel_t pick_bitslice(int L, int d, bool weighted)
 {
 #define GKM_BS(LL, DD) \
     if (L == LL && d == DD) return weighted ? k_gram_bitslice<W, LL, DD, true> : k_gram_bitslice<W, LL, DD, false>;
+    if (L == 11 && d == 3 && weighted) {
+        const char *v = getenv("GKM_VARIANT");
+        const int vi = v ? atoi(v) : 0;
+        if (vi == 1) return k_gram_bitslice<W, 11, 3, true, 1>;
+        if (vi == 2) return k_gram_bitslice<W, 11, 3, true, 2>;
+        if (vi == 4) return k_gram_bitslice<W, 11, 3, true, 4>;
+        if (vi == 5) return k_gram_bitslice<W, 11, 3, true, 5>;
+    }
     GKM_BS(10, 3)
     GKM_BS(11, 3)
     GKM_BS(12, 4)
@@ -620,23 +748,23 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
             tile_amax[k / 64] = std::max(tile_amax[k / 64], seg_seq[k]);
         if (ctx->seg_seq.ensure(seg_seq.size()) || ctx->seg_s0.ensure(seg_seq.size()) ||
             ctx->seg_slot.ensure(seg_seq.size()) || ctx->tile_amax.ensure((size_t)ntiles) ||
-            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64))
+            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64) || ctx->rowpk.ensure((size_t)ntiles * (2 * W + 1) * 64))
             return 4;
         HIPCHK(hipMemcpyAsync(ctx->seg_seq.p, seg_seq.data(), seg_seq.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->seg_s0.p, seg_s0.data(), seg_s0.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->seg_slot.p, seg_slot.data(), seg_slot.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, tile_amax.data(), tile_amax.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         /* the host vectors above are pageable: the copies have completed on return */
-        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p);
+        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
+                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p, ctx->rowpk.p);
         HIPCHK(hipGetLastError());
 
         BsArgs A;
-        A.rowplanes = ctx->rowplanes.p;
+        A.rowplanes = ctx->rowplanes.p; A.rowpk = ctx->rowpk.p; A.pk = ctx->pk.p; A.pkw = ctx->pkw;
         A.seg_seq = ctx->seg_seq.p; A.seg_s0 = ctx->seg_s0.p; A.seg_slot = ctx->seg_slot.p;
         A.tile_amax = ctx->tile_amax.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
-        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.wt = ctx->wt.p;
+        A.len = ctx->len.p; A.wd = ctx->wd.p; A.wd_len = ctx->wd_len;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 16;
@@ -655,7 +783,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
         DirectArgs A;
         A.rows = ctx->rows.p; A.nrows = nrows;
-        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.wt = ctx->wt.p;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.wd = ctx->wd.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 16; A.L = L; A.d = d;

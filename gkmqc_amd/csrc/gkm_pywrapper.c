@@ -28,8 +28,7 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     gkm_problem *prob = NULL;
     gkmhip_ctx *ctx = NULL;
     double *dG = NULL;
-    uint8_t *wt = NULL;
-    int64_t *wt_off = NULL;
+    uint8_t *wd = NULL;
     int *rows = NULL;
     const double t_start = now_ms();
 
@@ -95,33 +94,28 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         gkm_log(GKM_LOG_WARN, "maximum sequence length allowed is %d. Only the first %d nucleotides of %ld longer sequence(s) are used",
                 GKM_MAX_SEQ, GKM_MAX_SEQ, gkm_problem_truncated(prob));
 
-    /* positional weights, one table per distinct l-mer count, expanded per sequence */
-    wt_off = (int64_t *)malloc(sizeof(int64_t) * ((size_t)n + 1));
-    if (!wt_off) goto done;
-    wt_off[0] = 0;
+    /* positional weights: the reference's w(n, p) depends on n and p only through the
+     * distance |n/2 - p| to the centre l-mer (libgkm.c:912-925), so one table indexed by
+     * that distance serves every sequence length */
+    int maxn = 0;
     for (int i = 0; i < n; i++) {
         const int len = gkm_problem_seqlen(prob, i);
         if (len < L) { /* undefined behaviour in the reference (negative l-mer count) */
             gkm_log(GKM_LOG_ERROR, "sequence %d has %d nucleotides, fewer than L = %d", i, len, L);
             goto done;
         }
-        wt_off[i + 1] = wt_off[i] + (len - L + 1);
+        if (len - L + 1 > maxn) maxn = len - L + 1;
     }
+    int wd_len = 0;
     if (weighted) {
-        uint8_t *table[GKM_MAX_SEQ + 1];
-        memset(table, 0, sizeof table);
-        wt = (uint8_t *)malloc((size_t)wt_off[n]);
-        if (!wt) goto done;
-        for (int i = 0; i < n; i++) {
-            const int nl = gkm_problem_seqlen(prob, i) - L + 1;
-            if (!table[nl]) {
-                table[nl] = (uint8_t *)malloc((size_t)nl);
-                if (!table[nl]) goto done;
-                gkm_position_weights(kt, nl, opts->M, opts->H, table[nl]);
-            }
-            memcpy(wt + wt_off[i], table[nl], (size_t)nl);
-        }
-        for (int i = 0; i <= GKM_MAX_SEQ; i++) free(table[i]);
+        const int dmax = maxn / 2 + 1;
+        uint8_t *full = (uint8_t *)malloc((size_t)(2 * dmax + 1));
+        wd = (uint8_t *)malloc((size_t)dmax + 1);
+        if (!full || !wd) { free(full); goto done; }
+        gkm_position_weights(kt, 2 * dmax + 1, opts->M, opts->H, full); /* centre index = dmax */
+        memcpy(wd, full + dmax, (size_t)dmax + 1);
+        free(full);
+        wd_len = dmax + 1;
     }
     const double t_parsed = now_ms();
 
@@ -133,8 +127,7 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
         goto done;
     }
-    if (gkmhip_set_sequences(ctx, n, gkm_problem_all_codes(prob), gkm_problem_offsets(prob), wt, wt_off, weighted,
-                             NULL)) {
+    if (gkmhip_set_sequences(ctx, n, gkm_problem_all_codes(prob), gkm_problem_offsets(prob), wd, wd_len, NULL)) {
         gkm_log(GKM_LOG_ERROR, "device upload failed: %s", gkmhip_last_error());
         goto done;
     }
@@ -170,8 +163,7 @@ done:
     free(rows);
     if (dG) gkmhip_free(dG);
     if (ctx) gkmhip_destroy(ctx);
-    free(wt);
-    free(wt_off);
+    free(wd);
     gkm_problem_free(prob);
     return rc;
 }

@@ -85,7 +85,7 @@ def load():
     L.gkmhip_set_kernel.restype = i32
     L.gkmhip_set_kernel.argtypes = (vp, i32)
     L.gkmhip_set_sequences.restype = i32
-    L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, vp, i32, vp)
+    L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, i32, vp)
     L.gkmhip_gram_rows.restype = i32
     L.gkmhip_gram_rows.argtypes = (vp, vp, i32, i32, vp, i64, vp, i64, vp)
     L.gkmhip_normalize.restype = i32
@@ -129,6 +129,13 @@ def position_weights(kernel_type, n, M=50, H=50.0):
     out = np.zeros(max(n, 0), dtype=np.uint8)
     load().gkm_position_weights(kernel_type, n, M, float(H), out.ctypes.data)
     return out
+
+
+def distance_weights(kernel_type, max_n, M=50, H=50.0):
+    """wd[D] = positional weight of an l-mer at distance D from the centre l-mer; the
+    reference's w(n, p) (src/libgkm.c:912-925) equals wd[|n//2 - p|] for every n."""
+    dmax = max_n // 2 + 1
+    return np.ascontiguousarray(position_weights(kernel_type, 2 * dmax + 1, M, H)[dmax:])
 
 
 def read_problem(posfile, negfile):
@@ -203,20 +210,16 @@ class GramContext:
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(lens, out=off[1:])
         codes = np.concatenate(seqs).astype(np.uint8) if n else np.zeros(0, np.uint8)
-        wt = wt_off = None
+        if (lens < self.L).any():
+            raise GkmError("a sequence is shorter than L")
+        wd = None
         if self.weighted:
-            nl = lens - self.L + 1
-            if (nl <= 0).any():
-                raise GkmError("a sequence is shorter than L")
-            wt_off = np.zeros(n + 1, dtype=np.int64)
-            np.cumsum(nl, out=wt_off[1:])
-            tables = {int(v): position_weights(self.kernel_type, int(v), self.M, self.H) for v in np.unique(nl)}
-            wt = np.concatenate([tables[int(v)] for v in nl])
-        self._keep = (codes, off, wt, wt_off)
+            wd = distance_weights(self.kernel_type, int(lens.max()) - self.L + 1, self.M, self.H)
+        self._keep = (codes, off, wd)
         self._chk(self.lib.gkmhip_set_sequences(
             self.handle, n, codes.ctypes.data, off.ctypes.data,
-            wt.ctypes.data if wt is not None else None, wt_off.ctypes.data if wt_off is not None else None,
-            int(self.weighted), stream), "gkmhip_set_sequences")
+            wd.ctypes.data if wd is not None else None, len(wd) if wd is not None else 0, stream),
+            "gkmhip_set_sequences")
         self.n = n
         self.lens = lens
 

@@ -52,11 +52,13 @@ void gkmhip_destroy(gkmhip_ctx *ctx);
 int gkmhip_set_kernel(gkmhip_ctx *ctx, int which);
 
 /* Upload n sequences.  codes: base codes 0..3, concatenated; offsets[n+1] (elements).
- * wt: forward positional weights, concatenated, n_i = len_i - L + 1 per sequence;
- * wt_offsets[n+1].  weighted == 0 means all weights are 1 (wt may be NULL).
- * Builds every device table the kernels need (asynchronously on `stream`). */
+ * wdist: positional weights as a function of the distance to the centre l-mer: the
+ * weight of l-mer p of a sequence with n l-mers is wdist[|n/2 - p|] (this is all the
+ * reference's exponential-decay weights depend on, src/libgkm.c:912-925); it must cover
+ * distances 0..max(n)/2, at most 1024 entries.  wdist == NULL: all weights are 1.
+ * Uploads asynchronously on `stream`; device tables are built on first use. */
 int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
-                         const uint8_t *wt, const int64_t *wt_offsets, int weighted, void *stream);
+                         const uint8_t *wdist, int wdist_len, void *stream);
 
 /* Raw Gram values for the rows listed in `rows` (host array of nrows ascending sequence
  * indices): row rows[i] is written to G + i*ld (local_rows != 0) or to

@@ -30,19 +30,30 @@ def _oracle_profile(O, t, L, d, A, B):
     return P
 
 
+def _dist_table(O, t, nmax):
+    """wd[D] = positional weight at distance D from the centre l-mer (same for every length)."""
+    dmax = nmax // 2 + 1
+    wt = O.position_weights(t, 2 * dmax + 1)
+    return np.ascontiguousarray(wt[dmax:])
+
+
 def _probe_profile(O, probe, W, t, L, d, A, B):
     P = np.zeros(d + 1, dtype=np.int32)
     vp = ctypes.c_void_p
-    if t in (4, 5):
-        wa = O.position_weights(t, len(A) - L + 1)
-        wb = O.position_weights(t, len(B) - L + 1)
-        rc = probe.bsprobe_profile(W, L, d, A.ctypes.data_as(vp), len(A), wa.ctypes.data_as(vp),
-                                   B.ctypes.data_as(vp), len(B), wb.ctypes.data_as(vp), P.ctypes.data_as(vp))
-    else:
-        rc = probe.bsprobe_profile(W, L, d, A.ctypes.data_as(vp), len(A), None, B.ctypes.data_as(vp), len(B), None,
-                                   P.ctypes.data_as(vp))
+    wd = _dist_table(O, t, max(len(A), len(B))) if t in (4, 5) else None
+    rc = probe.bsprobe_profile(W, L, d, A.ctypes.data_as(vp), len(A), B.ctypes.data_as(vp), len(B),
+                               wd.ctypes.data_as(vp) if wd is not None else None, P.ctypes.data_as(vp))
     assert rc == 0
     return P
+
+
+def test_distance_table_reproduces_every_length(libs):
+    O, _ = libs
+    for n in (1, 2, 3, 17, 139, 290, 291, 589, 2036):
+        wd = _dist_table(O, 4, n)
+        want = O.position_weights(4, n)
+        got = np.array([wd[abs(n // 2 - p)] for p in range(n)], dtype=np.uint8)
+        assert (got == want).all(), n
 
 
 @pytest.mark.parametrize("W,L,d", CASES)
