@@ -270,9 +270,10 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     return x;
 }
 
-constexpr int BS_CAP = 16;     /* hit-queue entries per lane */
-constexpr int BS_SCAP = 384;    /* wave-wide compacted hit words per drain */
-constexpr int BS_PKW_MAX = 130; /* packed words per strand: ceil(2047/16) + 1 */
+constexpr int BS_CAP = 12;    /* hit-queue entries per lane */
+constexpr int BS_RING = 320;  /* wave-wide ring of compacted hit words */
+constexpr int BS_CHUNK = 192; /* words compacted into the ring at a time */
+constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
 constexpr int BS_DU = 5;   /* shifts per SB register refill */
 
 /*
@@ -289,16 +290,18 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
     using namespace gkmbs;
-    __shared__ uint32_t q_h[BS_CAP * 64];        /* per-lane hit queue: hit word ...              */
-    __shared__ uint32_t q_meta[BS_CAP * 64];     /* ... and where it came from (w, delta, strand) */
-    __shared__ uint32_t s_h[BS_SCAP];            /* wave-wide compacted list of hit words ...     */
-    __shared__ uint32_t s_meta[BS_SCAP];         /* ... with origin incl. the source lane         */
-    __shared__ uint32_t rowpk[(2 * W + 1) * 64]; /* every lane's segment, 2-bit packed            */
-    __shared__ uint32_t rowinfo[64];             /* s0 | centre << 12 of every lane               */
-    __shared__ uint32_t colpk[2 * BS_PKW_MAX];   /* both strands of the current column sequence   */
-    __shared__ uint32_t accl[(D + 1) * 64];      /* mismatch profile accumulators [m][lane]       */
-    __shared__ uint32_t wdl32[WEIGHTED ? WD_LDS / 4 : 1];
-    const uint8_t *wdl = (const uint8_t *)wdl32;
+    /* LDS per wave: 6 KB queue + 2.5 KB ring + 1.25 KB accumulators = 9.75 KB -> 16 waves per CU.
+     * The read-mostly tables (packed segments/strands, weight table) stay in global memory:
+     * they are a few KB per wave and L1/L2 resident; keeping them out of LDS buys occupancy,
+     * which is what hides the latency of the drain (measured: 301 -> 244 ms on config 2). */
+    __shared__ uint32_t q_h[BS_CAP * 64];    /* per-lane hit queue: hit word ...                */
+    __shared__ uint32_t q_meta[BS_CAP * 64]; /* ... and where it came from (w, delta, strand)   */
+    __shared__ uint32_t s_h[BS_RING];        /* wave-wide ring of compacted hit words ...       */
+    __shared__ uint32_t s_meta[BS_RING];     /* ... with origin incl. the source lane           */
+    __shared__ uint32_t rowinfo[64];         /* s0 | centre << 12 of every lane                 */
+    __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]         */
+    constexpr int HALF = (W + 1) / 2;        /* the queue is checked twice per shift            */
+    static_assert(BS_CAP > HALF + 2, "queue too small for W");
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
@@ -307,13 +310,8 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int j1 = min(j0 + A.cj, amax + 1);
     if (j0 >= j1) return;
 
-    /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
-    if (WEIGHTED) {
-        const uint32_t *src = (const uint32_t *)A.wd;
-        for (int i = lane; i < WD_LDS / 4; i += 64) wdl32[i] = src[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2 * W + 1; i++) rowpk[i * 64 + lane] = A.rowpk[((size_t)tile * (2 * W + 1) + i) * 64 + lane];
+    const uint8_t *wdg = A.wd;
+    const uint32_t *rowpk_g = A.rowpk + (size_t)tile * (2 * W + 1) * 64;
 
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
@@ -326,18 +324,19 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int s0 = A.seg_s0[tile * 64 + lane];
     const int slot = A.seg_slot[tile * 64 + lane];
     const int cA = myseq >= 0 ? (A.len[myseq] - L + 1) / 2 : 0; /* centre l-mer, libgkm.c:912 */
+    /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
     rowinfo[lane] = (uint32_t)s0 | ((uint32_t)cA << 12);
     const uint32_t lane_tag = (uint32_t)lane << 18;
 
-    auto wt_at = [&](int dist) { return (uint32_t)wdl[dist]; };
+    auto wt_at = [&](int dist) { return (uint32_t)wdg[dist]; };
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
         const int pkw = A.pkw;
-        for (int i = lane; i < 2 * pkw; i += 64) colpk[i] = A.pk[(size_t)(j * 2) * pkw + i];
-        auto col_word = [&](int strand, int i) { return colpk[strand * pkw + i]; };
+        const uint32_t *colpk_g = A.pk + (size_t)(j * 2) * pkw;
+        auto col_word = [&](int strand, int i) { return colpk_g[strand * pkw + i]; };
 #pragma unroll
         for (int k = 0; k <= D; k++) accl[k * 64 + lane] = 0u;
         int qn = 0;
@@ -346,74 +345,68 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
         auto resolve = [&](uint32_t rec) {
             const int r = rec_lane(rec);
             const uint32_t info = rowinfo[r];
-            auto row_word = [&](int i) { return rowpk[i * 64 + r]; };
+            auto row_word = [&](int i) { return rowpk_g[i * 64 + r]; };
             const HitValue hv = resolve_hit<W, L, WEIGHTED>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec),
                                                             (int)(info & 4095u), (uint32_t)T, rcpT, (int)(info >> 12), nB,
                                                             row_word, col_word, wt_at);
             atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
-        /* Compact the per-lane queues of hit words into one wave-wide list (prefix sum of the
-         * queue lengths over the lanes, on DPP), then resolve the list 2 x 64 words at a time with
-         * every lane busy.  A word with more than one hit bit has its remaining bits appended to
-         * the list again.  If the list would not fit (dense, repeat-like input) each lane
-         * resolves its own queue instead: slower, same result. */
+        /* Compact the per-lane queues of hit words into a wave-wide ring (prefix sum of the queue
+         * lengths over the lanes, on DPP; up to BS_CHUNK words at a time, whole lanes only), then
+         * resolve the ring 2 x 64 words per trip with every lane busy: each word gives up its
+         * lowest hit bit, what is left of a multi-hit word is appended to the ring again. */
         auto drain = [&]() {
             const int incl = wave_inclusive_scan(qn);
-            int total = __builtin_amdgcn_readlane(incl, 63);
-            if (total <= BS_SCAP - 128) {
-                int pos = incl - qn;
-                for (int e = 0; __any(e < qn); e++) {
-                    if (e < qn) {
-                        s_h[pos] = q_h[e * 64 + lane];
-                        s_meta[pos] = q_meta[e * 64 + lane] | lane_tag;
-                        pos++;
+            const int excl = incl - qn;
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            int lo = 0;
+            while (lo < total) {
+                const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + BS_CHUNK);
+                const unsigned long long pm = __ballot(part);
+                const int last = 63 - __builtin_clzll(pm);
+                const int hi = __builtin_amdgcn_readlane(incl, last);
+                for (int e = 0; __any(part && e < qn); e++) {
+                    if (part && e < qn) {
+                        const int p = excl - lo + e;
+                        s_h[p] = q_h[e * 64 + lane];
+                        s_meta[p] = q_meta[e * 64 + lane] | lane_tag;
                     }
                 }
-                for (int i0 = 0; i0 < total;) {
-                    /* this trip covers the words present now; re-appended ones land at >= lim */
-                    const int lim = min(total, i0 + 128);
+                int hd = 0, n = hi - lo;
+                while (n > 0) {
+                    const int c = min(n, BS_TRIP);
                     uint32_t left[2], meta[2];
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
-                        const int idx = i0 + k * 64 + lane;
-                        const uint32_t h = (idx < lim) ? s_h[idx] : 0u;
-                        meta[k] = s_meta[min(idx, BS_SCAP - 1)];
+                        const int i = k * 64 + lane;
+                        int p = hd + i;
+                        p -= (p >= BS_RING) ? BS_RING : 0;
+                        const uint32_t h = (i < c) ? s_h[p] : 0u;
+                        meta[k] = s_meta[p];
                         if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
                         left[k] = h & (h - 1u);
                     }
+                    int appended = 0;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const unsigned long long more = __ballot(left[k] != 0u);
-                        if (more) { /* re-append what is left of multi-hit words (rare per lane) */
-                            const int at = total + __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                            if (left[k] != 0u && at < BS_SCAP) {
+                        if (more) {
+                            int at = hd + n + appended + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                            at -= (at >= BS_RING) ? BS_RING : 0;
+                            if (left[k] != 0u) {
                                 s_h[at] = left[k];
                                 s_meta[at] = meta[k];
-                            } else if (left[k] != 0u) { /* no room: finish this word here */
-                                uint32_t h = left[k];
-                                while (h) {
-                                    resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
-                                    h &= h - 1u;
-                                }
                             }
-                            total = min(total + (int)__popcll(more), BS_SCAP);
+                            appended += (int)__popcll(more);
                         }
                     }
-                    i0 = lim;
+                    hd += c;
+                    hd -= (hd >= BS_RING) ? BS_RING : 0;
+                    n += appended - c;
                 }
-            } else {
-                for (int e = 0; __any(e < qn); e++) {
-                    if (e < qn) {
-                        uint32_t h = q_h[e * 64 + lane];
-                        const uint32_t base = q_meta[e * 64 + lane] | lane_tag;
-                        while (h) {
-                            resolve(base | ((uint32_t)__builtin_ctz(h) << 24));
-                            h &= h - 1u;
-                        }
-                    }
-                }
+                lo = hi;
             }
             qn = 0;
         };
@@ -449,10 +442,12 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                                 q_h[qn * 64 + lane] = h;
                                 q_meta[qn * 64 + lane] = pack_meta(d0 + u, w, strand);
                                 qn += (h != 0u) ? 1 : 0;
+                                if (w == HALF - 1 || w == W - 1) {
+                                    if ((VARIANT & 3) == 2) { if (__any(qn > BS_CAP - HALF)) qn = 0; }
+                                    else if (__any(qn > BS_CAP - HALF)) drain();
+                                }
                             }
                         }
-                        if ((VARIANT & 3) == 2) { if (__any(qn > BS_CAP - W)) qn = 0; }
-                        else if (__any(qn > BS_CAP - W)) drain();
                     }
                 }
             }
