@@ -25,8 +25,42 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_INT32_GOPS = 256 * 64 * 2.4  # CUs x lanes x GHz = 39321.6 Gop/s
+# Integer-VALU peak of MI355X: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78 643 Gop/s.
+# (tools/valu_peak.hip measures 65-72 Tera lane-ops/s for full-rate VOP2 ops on the box, i.e. a
+# wave64 v_xor_b32 every ~2.2 cycles per SIMD; SURVEY.md §8(d) assumed 16 lanes/clk = 39 321.)
+PEAK_INT32_GOPS = 256 * 4 * 32 * 2.4
 OPS_PER_COMPARISON = 6            # op model of SURVEY.md §8(d): xor, shift, or, and, popcount, compare
+
+
+def host_cores():
+    """Cores this process may really use: affinity clipped by the cgroup CPU quota (the GPU
+    box exposes 256 logical CPUs but grants a 16-CPU share per GPU)."""
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return cores
+
+
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (separate FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); None if absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(args, L, k, d, kernel_type):
@@ -35,11 +69,7 @@ def cpu_baseline(args, L, k, d, kernel_type):
     the C restatement (kind "port") if the reference build did not travel."""
     from gkmqc_amd import synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     npos = nneg = args.cpu_sample
     tmp = tempfile.mkdtemp(prefix="gkm_bench_")
     pf, nf = os.path.join(tmp, "p.fa"), os.path.join(tmp, "n.fa")
@@ -117,8 +147,6 @@ def main():
     full = torch.zeros((n, n), dtype=torch.float64, device=dev)
     sq = torch.zeros(n, dtype=torch.float64, device=dev)
 
-    kernel_ms = []
-
     def step():
         if world == 1:
             ctx.gram_rows(rows, full.data_ptr(), n, None, 0, False, stream)
@@ -139,7 +167,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(None)  # filled below from HIP events (queried after the timed region)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -157,7 +184,6 @@ def main():
             ctx.gram_rows(rows, slab.data_ptr(), n, None, 0, True, stream)
         torch.cuda.synchronize(dev)
         durs.append(ctx.last_kernel_ms())
-    ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream) if world == 1 else None
     kern_ms = float(np.mean(durs))
     comparisons = ctx.last_comparisons()       # 2 n_a n_j summed over this rank's (a, j<=a) pairs
     kname = ctx.last_kernel_name()
@@ -186,15 +212,19 @@ def main():
     }
     if rank == 0:
         achieved = comparisons * OPS_PER_COMPARISON / (kern_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic()
         out["roofline"] = {
             "bound": "valu",
             "achieved": achieved, "peak": PEAK_INT32_GOPS, "unit": "Gop/s", "frac": achieved / PEAK_INT32_GOPS,
-            "traffic": None,
+            "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kname, "kernel_ms": kern_ms, "comparisons_per_launch": comparisons,
-            "note": "integer-VALU bound (SURVEY.md §8(d)): algorithmic ops = 6 int32 ops per l-mer comparison x "
-                    "2 n_a n_j comparisons per pair; peak = 256 CU x 64 lanes x 2.4 GHz. The bit-sliced kernel "
-                    "EXECUTES ~1.3 ops per comparison, so frac can exceed what an l-mer-by-l-mer kernel could reach; "
-                    "HBM traffic is negligible for this path (see DESIGN.md)",
+            "hbm_achieved_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+            "note": "This path is integer-VALU bound, neither HBM nor MFMA (SURVEY.md §8(d)); bound says so. "
+                    "achieved = ALGORITHMIC ops: 6 int32 ops per l-mer comparison (SURVEY op model) x "
+                    "comparisons_per_launch (2 n_a n_j per pair, this rank's pairs) / kernel_ms (HIP events on the "
+                    "launch stream). peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz. The bit-sliced kernel EXECUTES "
+                    "about 1 VALU op per comparison instead of 6, which is why frac exceeds 1: see DESIGN.md for "
+                    "the executed-instruction utilisation from rocprofv3 (profiles/). HBM traffic is incidental.",
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.L, args.k, args.d, args.kernel_type)
