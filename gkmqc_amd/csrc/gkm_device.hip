@@ -353,37 +353,46 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
         };
 
         /* Compact the per-lane queues of hit words into a wave-wide ring (prefix sum of the queue
-         * lengths over the lanes, on DPP; up to BS_CHUNK words at a time, whole lanes only), then
-         * resolve the ring 2 x 64 words per trip with every lane busy: each word gives up its
-         * lowest hit bit, what is left of a multi-hit word is appended to the ring again. */
-        auto drain = [&]() {
+         * lengths over the lanes, on DPP; whole lanes only, as many as fit), then resolve the ring
+         * in FULL trips of 2 x 64 words with every lane busy: each word gives up its lowest hit
+         * bit, what is left of a multi-hit word is appended to the ring again.  Fewer than one
+         * trip's worth of words stays in the ring for the next drain; the last drain of a column
+         * (final) empties it. */
+        int ring_hd = 0, ring_n = 0;
+        auto drain = [&](bool final) {
             const int incl = wave_inclusive_scan(qn);
             const int excl = incl - qn;
             const int total = __builtin_amdgcn_readlane(incl, 63);
             int lo = 0;
-            while (lo < total) {
-                const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + BS_CHUNK);
-                const unsigned long long pm = __ballot(part);
-                const int last = 63 - __builtin_clzll(pm);
-                const int hi = __builtin_amdgcn_readlane(incl, last);
-                for (int e = 0; __any(part && e < qn); e++) {
-                    if (part && e < qn) {
-                        const int p = excl - lo + e;
-                        s_h[p] = q_h[e * 64 + lane];
-                        s_meta[p] = q_meta[e * 64 + lane] | lane_tag;
+            do {
+                if (lo < total) { /* invariant here: ring_n < BS_TRIP, so at least one lane fits */
+                    const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + (BS_RING - ring_n));
+                    const unsigned long long pm = __ballot(part);
+                    const int last = 63 - __builtin_clzll(pm);
+                    const int hi = __builtin_amdgcn_readlane(incl, last);
+                    int p = ring_hd + ring_n + (excl - lo);
+                    p -= (p >= BS_RING) ? BS_RING : 0;
+                    for (int e = 0; __any(part && e < qn); e++) {
+                        if (part && e < qn) {
+                            s_h[p] = q_h[e * 64 + lane];
+                            s_meta[p] = q_meta[e * 64 + lane] | lane_tag;
+                            p++;
+                            p -= (p >= BS_RING) ? BS_RING : 0;
+                        }
                     }
+                    ring_n += hi - lo;
+                    lo = hi;
                 }
-                int hd = 0, n = hi - lo;
-                while (n > 0) {
-                    const int c = min(n, BS_TRIP);
+                while (ring_n >= BS_TRIP || (final && lo >= total && ring_n > 0)) {
+                    const int c = min(ring_n, BS_TRIP);
                     uint32_t left[2], meta[2];
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const int i = k * 64 + lane;
-                        int p = hd + i;
-                        p -= (p >= BS_RING) ? BS_RING : 0;
-                        const uint32_t h = (i < c) ? s_h[p] : 0u;
-                        meta[k] = s_meta[p];
+                        int q = ring_hd + i;
+                        q -= (q >= BS_RING) ? BS_RING : 0;
+                        const uint32_t h = (i < c) ? s_h[q] : 0u;
+                        meta[k] = s_meta[q];
                         if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
                         left[k] = h & (h - 1u);
                     }
@@ -392,8 +401,10 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                     for (int k = 0; k < 2; k++) {
                         const unsigned long long more = __ballot(left[k] != 0u);
                         if (more) {
-                            int at = hd + n + appended + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                            int at = ring_hd + ring_n + appended +
+                                     (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                            at -= (at >= BS_RING) ? BS_RING : 0;
                             at -= (at >= BS_RING) ? BS_RING : 0;
                             if (left[k] != 0u) {
                                 s_h[at] = left[k];
@@ -402,12 +413,11 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                             appended += (int)__popcll(more);
                         }
                     }
-                    hd += c;
-                    hd -= (hd >= BS_RING) ? BS_RING : 0;
-                    n += appended - c;
+                    ring_hd += c;
+                    ring_hd -= (ring_hd >= BS_RING) ? BS_RING : 0;
+                    ring_n += appended - c;
                 }
-                lo = hi;
-            }
+            } while (lo < total);
             qn = 0;
         };
 
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                                 qn += (h != 0u) ? 1 : 0;
                                 if (w == HALF - 1 || w == W - 1) {
                                     if ((VARIANT & 3) == 2) { if (__any(qn > BS_CAP - HALF)) qn = 0; }
-                                    else if (__any(qn > BS_CAP - HALF)) drain();
+                                    else if (__any(qn > BS_CAP - HALF)) drain(false);
                                 }
                             }
                         }
@@ -452,7 +462,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                 }
             }
         }
-        drain();
+        drain(true);
 
         uint32_t acc[D + 1];
 #pragma unroll
