@@ -188,6 +188,36 @@ GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
     }
 }
 
+constexpr int TT_A_AND_BXC = 0x60; /* a & (b ^ c) */
+
+/* sum of N one-bit planes as an exact bit-sliced count (carry-save adder tree: 2 ops per
+ * full adder).  Used once per shift for the first window. */
+template <int NB, int N>
+struct PlaneSum {
+    static GKM_HD Cnt<NB, N> run(const uint32_t *z)
+    {
+        if constexpr (N == 1) {
+            Cnt<NB, 1> r;
+            r.b[0] = z[0];
+            r.ovf = 0u;
+            return r;
+        } else if constexpr (N == 2) {
+            Cnt<NB, 1> x, y;
+            x.b[0] = z[0]; x.ovf = 0u;
+            y.b[0] = z[1]; y.ovf = 0u;
+            return cnt_add<false>(x, y);
+        } else if constexpr (N == 3) {
+            Cnt<NB, 1> x, y;
+            x.b[0] = z[0]; x.ovf = 0u;
+            y.b[0] = z[1]; y.ovf = 0u;
+            return cnt_add<true>(x, y, z[2]);
+        } else {
+            constexpr int H = ((N - 1) / 2);          /* two halves + one carry-in plane */
+            return cnt_add<true>(PlaneSum<NB, H>::run(z), PlaneSum<NB, N - 1 - H>::run(z + H), z[N - 1]);
+        }
+    }
+};
+
 /*
  * One cyclic shift of one column strand against one row segment.
  *   Ahi/Alo/AV : the segment's planes, W words each (per lane)
@@ -195,12 +225,19 @@ GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
  * For w in [0,W): hit[w] = windows (bit b <-> segment base b*W + w) with <= D mismatches
  * whose start is valid on both sides.  The exact count of a hit is recomputed from the
  * packed l-mers when the hit is consumed (cheaper than carrying the count planes along).
+ *
+ * Window counts: the first window (w = 0) is summed with an adder tree; every further window
+ * differs from its left neighbour by one base entering and one leaving, so the exact
+ * bit-sliced count is stepped by an up/down counter, 2 ops per count plane:
+ *     d = Zin ^ Zout;  t_0 = d;  b_i ^= t_i;  t_{i+1} = t_i & (b_i_old ^ Zout)
+ * (carry when counting up through a 1, borrow when counting down through a 0).
  */
 template <int W, int L, int D>
 GKM_HD void window_hits(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t *AV, const uint32_t *Bhi,
                         const uint32_t *Blo, const uint32_t *Bv, uint32_t *hit)
 {
-    constexpr int NB = planes_for(D);
+    static_assert(L >= 2 && L <= 12, "L out of range");
+    constexpr int P = bitlen(L); /* planes of an exact count 0..L */
     constexpr int NX = W + L - 1;
     uint32_t Z[NX];
 #pragma unroll
@@ -208,38 +245,20 @@ GKM_HD void window_hits(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t
 #pragma unroll
     for (int x = W; x < NX; x++) Z[x] = Z[x - W] >> 1; /* word x == word x-W one bit up */
 
-    /* sliding power-of-two window sums; levels L does not use are dead code */
-    Cnt<NB, 1> s1[NX];
-    Cnt<NB, 2> s2[NX];
-    Cnt<NB, 4> s4[NX];
-    Cnt<NB, 8> s8[NX];
-#pragma unroll
-    for (int x = 0; x < NX; x++) { s1[x].b[0] = Z[x]; s1[x].ovf = 0u; }
-#pragma unroll
-    for (int x = 0; x + 1 < NX; x++) s2[x] = cnt_add<false>(s1[x], s1[x + 1]);
-#pragma unroll
-    for (int x = 0; x + 3 < NX; x++) s4[x] = cnt_add<false>(s2[x], s2[x + 2]);
-#pragma unroll
-    for (int x = 0; x + 7 < NX; x++) s8[x] = cnt_add<false>(s4[x], s4[x + 4]);
-
+    Cnt<P, L> cnt = PlaneSum<P, L>::run(Z);
 #pragma unroll
     for (int w = 0; w < W; w++) {
-        /* L = 8*e8 + 4*e4 + 2*e2 + e1: add the blocks left to right; a trailing single base
-         * rides as the carry-in of the last two-operand add */
-        Cnt<NB, L> tot;
-        if constexpr (L == 12) tot = cnt_add<false>(s8[w], s4[w + 8]);
-        else if constexpr (L == 11) tot = cnt_add<true>(s8[w], s2[w + 8], Z[w + 10]);
-        else if constexpr (L == 10) tot = cnt_add<false>(s8[w], s2[w + 8]);
-        else if constexpr (L == 9) tot = cnt_add<false>(s8[w], s1[w + 8]);
-        else if constexpr (L == 8) tot = s8[w];
-        else if constexpr (L == 7) tot = cnt_add<true>(s4[w], s2[w + 4], Z[w + 6]);
-        else if constexpr (L == 6) tot = cnt_add<false>(s4[w], s2[w + 4]);
-        else if constexpr (L == 5) tot = cnt_add<false>(s4[w], s1[w + 4]);
-        else if constexpr (L == 4) tot = s4[w];
-        else if constexpr (L == 3) tot = cnt_add<false>(s2[w], s1[w + 2]);
-        else tot = s2[w];
-        static_assert(L >= 2 && L <= 12, "L out of range");
-        hit[w] = lop3<TT_NA_B_C>(cnt_exceeds<D>(tot), AV[w], Bv[w]);
+        if (w > 0) {
+            const uint32_t zout = Z[w - 1], zin = Z[w + L - 1];
+            uint32_t t = zin ^ zout;
+#pragma unroll
+            for (int i = 0; i < P; i++) {
+                const uint32_t old = cnt.b[i];
+                cnt.b[i] = old ^ t;
+                if (i + 1 < P) t = lop3<TT_A_AND_BXC>(t, old, zout);
+            }
+        }
+        hit[w] = lop3<TT_NA_B_C>(cnt_exceeds<D>(cnt), AV[w], Bv[w]);
     }
 }
 
