@@ -28,21 +28,22 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
             for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
         }
     const uint32_t rcpT = mod_magic((uint32_t)T);
-    const int pkw = (T + 15) / 16 + 1;
-    std::vector<uint32_t> colpk((size_t)2 * pkw);
-    for (int st = 0; st < 2; st++)
-        for (int i = 0; i < pkw; i++) colpk[(size_t)st * pkw + i] = strand_pack_word(B, T, st, i);
+    auto weight = [&](int n, int p) { return wd ? (uint32_t)wd[n / 2 > p ? n / 2 - p : p - n / 2] : 1u; };
+    std::vector<uint32_t> lmA((size_t)nA), lmB[2];
+    for (int p = 0; p < nA; p++) lmA[(size_t)p] = lmer_entry(A, lenA, L, 0, p, weight(nA, p));
+    for (int st = 0; st < 2; st++) {
+        lmB[st].resize((size_t)nB);
+        for (int q = 0; q < nB; q++) lmB[st][(size_t)q] = lmer_entry(B, lenB, L, st, q, weight(nB, st ? nB - 1 - q : q));
+    }
     for (int s0 = 0; s0 < nA; s0 += CAP) {
-        uint32_t Ahi[W], Alo[W], AV[W], rowpk[2 * W + 1];
+        uint32_t Ahi[W], Alo[W], AV[W];
         for (int w = 0; w < W; w++) {
             Ahi[w] = row_plane_word(A, lenA, s0, w, W, L, 0);
             Alo[w] = row_plane_word(A, lenA, s0, w, W, L, 1);
             AV[w] = row_plane_word(A, lenA, s0, w, W, L, 2);
         }
-        for (int i = 0; i < 2 * W + 1; i++) rowpk[i] = row_pack_word(A, lenA, s0, i);
-        auto rp = [&](int i) { return rowpk[i]; };
-        auto cp = [&](int st, int i) { return colpk[(size_t)st * pkw + i]; };
-        auto wt = [&](int dist) { return (uint32_t)wd[dist]; };
+        auto rl = [&](int i0) { return lmA[(size_t)(s0 + i0)]; };
+        auto cl = [&](int st, int q) { return lmB[st][(size_t)q]; };
         for (int st = 0; st < 2; st++)
             for (int delta = 0; delta < T; delta++) {
                 uint32_t hit[W];
@@ -53,8 +54,7 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
                     while (h) {
                         const int bit = __builtin_ctz(h);
                         h &= h - 1u;
-                        const HitValue hv = wd ? resolve_hit<W, L, true>(bit, w, delta, st, s0, (uint32_t)T, rcpT, nA / 2, nB, rp, cp, wt)
-                                               : resolve_hit<W, L, false>(bit, w, delta, st, s0, (uint32_t)T, rcpT, nA / 2, nB, rp, cp, wt);
+                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, rl, cl);
                         acc[hv.m] += hv.v;
                     }
                 }

@@ -325,64 +325,42 @@ GKM_HD uint32_t dist_weight(const uint8_t *wd, int center, int p)
     return wd[dd < 0 ? -dd : dd];
 }
 
-/* 2-bit packed bases, 16 per word, base i at bits 2*(i%16)..+1 of word i/16 */
-GKM_HD uint32_t row_pack_word(const uint8_t *codes, int len, int s0, int widx)
+/* l-mer table entry: the L bases as 2 bits each (first base in the highest pair, as a
+ * number in base 4) in bits 0..23, the positional weight of that l-mer in bits 24..31 */
+GKM_HD uint32_t lmer_entry(const uint8_t *codes, int len, int L, int strand, int p, uint32_t weight)
 {
     uint32_t v = 0u;
-    for (int k = 0; k < 16; k++) {
-        const int pos = s0 + widx * 16 + k;
-        if (pos < len) v |= (uint32_t)codes[pos] << (2 * k);
+    for (int i = 0; i < L; i++) {
+        const uint32_t c = strand ? (3u - codes[len - 1 - (p + i)]) : codes[p + i];
+        v = (v << 2) | c;
     }
-    return v;
-}
-GKM_HD uint32_t strand_pack_word(const uint8_t *codes, int T, int strand, int widx)
-{
-    uint32_t v = 0u;
-    for (int k = 0; k < 16; k++) {
-        const int q = widx * 16 + k;
-        if (q < T) v |= (uint32_t)(strand ? (3u - codes[T - 1 - q]) : codes[q]) << (2 * k);
-    }
-    return v;
-}
-/* the L bases starting at base `pos`, given the two packed words that hold them */
-GKM_HD uint32_t lmer_bits(uint32_t w0, uint32_t w1, int pos, int L)
-{
-    const int sh = (pos & 15) * 2;
-#if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t v = __builtin_amdgcn_alignbit(w1, w0, (uint32_t)sh);
-#else
-    const uint32_t v = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
-#endif
-    return v & ((1u << (2 * L)) - 1u);
+    return v | (weight << 24);
 }
 GKM_HD int lmer_mismatch(uint32_t x, uint32_t y)
 {
-    uint32_t t = x ^ y;
-    t = (t | (t >> 1)) & 0x55555555u;
+    uint32_t t = (x ^ y) & 0x00FFFFFFu;
+    t = (t | (t >> 1)) & 0x00555555u;
     return __builtin_popcount(t);
 }
 
 /* Resolve one hit: bit b of the hit word of (delta, w, strand) against a row segment.
- *   row window start  p = s0 + b*W + w           (weight wd[|cA - p|])
- *   column l-mer      q = (b*W + w + delta) mod T on `strand`
- *                     (weight wd[|cB - q|] forward, wd[|cB - (nB-1-q)|] reverse: libgkm.c:924)
+ *   row window start  p = s0 + b*W + w,  column l-mer q = (b*W + w + delta) mod T on `strand`
  * Returns m = Hamming distance of the two l-mers (<= d for a true hit) and v = wa*wb, the
- * amount the reference adds to mmprofile[m] (libgkm.c:338).
- *   rowpk(i)         packed word i of the row segment
- *   colpk(strand, i) packed word i of the column strand
- *   wt(dist)         positional weight at distance dist from the centre l-mer */
+ * amount the reference adds to mmprofile[m] (libgkm.c:338); the weights ride in the top
+ * byte of the l-mer table entries (forward: wt[q], reverse strand: wt_rc[q] = wt[n-1-q],
+ * libgkm.c:924).
+ *   rowlm(i0)        table entry of the row's l-mer at segment offset i0
+ *   collm(strand, q) table entry of the column strand's l-mer q */
 struct HitValue {
     int m;
     uint32_t v;
 };
-template <int W, int L, bool WEIGHTED, class RowPk, class ColPk, class Wt>
-GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, int s0, uint32_t T, uint32_t rcpT, int cA, int nB,
-                            RowPk rowpk, ColPk colpk, Wt wt)
+template <int W, class RowLm, class ColLm>
+GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, uint32_t T, uint32_t rcpT, RowLm rowlm, ColLm collm)
 {
     HitValue r;
     const int i0 = b * W + w;
-    const uint32_t la = lmer_bits(rowpk(i0 >> 4), rowpk((i0 >> 4) + 1), i0, L);
-    uint32_t x = (uint32_t)(i0 + delta);
+    const uint32_t x = (uint32_t)(i0 + delta);
     int q;
     if (T >= (uint32_t)(32 * W)) { /* x < 2T: one conditional subtraction (uniform test) */
         const uint32_t y = x - T;
@@ -390,13 +368,9 @@ GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, int s0, uint32_
     } else {
         q = (int)mod_small(x, T, rcpT);
     }
-    const uint32_t lb = lmer_bits(colpk(strand, q >> 4), colpk(strand, (q >> 4) + 1), q, L);
-    r.m = lmer_mismatch(la, lb);
-    r.v = 1u;
-    if (WEIGHTED) {
-        const int da = cA - (s0 + i0), db = nB / 2 - (strand ? (nB - 1 - q) : q);
-        r.v = wt(da < 0 ? -da : da) * wt(db < 0 ? -db : db);
-    }
+    const uint32_t ea = rowlm(i0), eb = collm(strand, q);
+    r.m = lmer_mismatch(ea, eb);
+    r.v = (ea >> 24) * (eb >> 24);
     return r;
 }
 

@@ -96,12 +96,12 @@ struct gkmhip_ctx {
     int wd_len = 0;
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
-    DevBuf<uint32_t> lmf, lmr, sb, pk; /* pk: 2-bit packed strands, 16 bases per word */
-    int sb_xw = 0, sb_W = 0, pkw = 0;
+    DevBuf<uint32_t> lmf, lmr, sb;
+    int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch */
     DevBuf<int> rows, seg_seq, seg_s0, seg_slot, tile_amax;
-    DevBuf<uint32_t> rowplanes, rowpk;
+    DevBuf<uint32_t> rowplanes;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -149,8 +149,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
-    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release(); ctx->pk.release();
-    ctx->rowpk.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
     ctx->rows.release(); ctx->seg_seq.release(); ctx->seg_s0.release(); ctx->seg_slot.release();
     ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -168,11 +167,13 @@ extern "C" int gkmhip_set_kernel(gkmhip_ctx *ctx, int which)
 }
 
 /* ----------------------------------------------------------- prep kernels */
-/* one workgroup per sequence; 2-bit packed l-mers of the forward strand and of the
- * reverse-complement strand (rc l-mer p = l-mer p of rc(seq), libgkm.c:877-888) */
+/* one workgroup per sequence: l-mer table entries (gkm_bitslice.h lmer_entry) of the forward
+ * strand and of the reverse-complement strand (rc l-mer p = l-mer p of rc(seq),
+ * libgkm.c:877-888), each with its positional weight in the top byte: wt[p] = wd[|n/2 - p|],
+ * wt_rc[p] = wt[n-1-p] (libgkm.c:912-925); all weights 1 for the unweighted kernel types */
 __global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
-                             const int64_t *__restrict__ lmoff, int L, uint32_t *__restrict__ lmf,
-                             uint32_t *__restrict__ lmr)
+                             const int64_t *__restrict__ lmoff, int L, const uint8_t *__restrict__ wd,
+                             int weighted, uint32_t *__restrict__ lmf, uint32_t *__restrict__ lmr)
 {
     const int s = blockIdx.x;
     const uint8_t *seq = codes + off[s];
@@ -180,51 +181,36 @@ __global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *_
     const int n = len - L + 1;
     const int64_t o = lmoff[s];
     for (int p = threadIdx.x; p < n; p += blockDim.x) {
-        uint32_t f = 0, r = 0;
-        for (int i = 0; i < L; i++) {
-            f = (f << 2) | seq[p + i];
-            r = (r << 2) | (3u - seq[len - 1 - (p + i)]);
-        }
-        lmf[o + p] = f;
-        lmr[o + p] = r;
+        const uint32_t wf = weighted ? gkmbs::dist_weight(wd, n / 2, p) : 1u;
+        const uint32_t wr = weighted ? gkmbs::dist_weight(wd, n / 2, n - 1 - p) : 1u;
+        lmf[o + p] = gkmbs::lmer_entry(seq, len, L, 0, p, wf);
+        lmr[o + p] = gkmbs::lmer_entry(seq, len, L, 1, p, wr);
     }
 }
 
-/* grid (sequence*2+strand, plane 0..3); threads over words.  planes 0..2: the strand's SB
- * table (strided bit planes); plane 3: the strand as 2-bit packed bases (pk, pkw words) */
+/* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
 __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
-                           int L, int xw, uint32_t *__restrict__ sb, int pkw, uint32_t *__restrict__ pk)
+                           int L, int xw, uint32_t *__restrict__ sb)
 {
     const int e = blockIdx.x, plane = blockIdx.y;
     const int s = e >> 1, strand = e & 1;
     const uint8_t *seq = codes + off[s];
     const int T = (int)(off[s + 1] - off[s]);
-    if (plane == 3) {
-        for (int i = threadIdx.x; i < pkw; i += blockDim.x)
-            pk[(size_t)e * pkw + i] = gkmbs::strand_pack_word(seq, T, strand, i);
-        return;
-    }
     uint32_t *dst = sb + ((size_t)e * 3 + plane) * xw;
     for (int x = threadIdx.x; x < xw; x += blockDim.x)
         dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
 }
 
-/* grid (tile, plane 0..3); 64 threads = the tile's lanes.  planes 0..2: bit planes,
- * layout [tile][plane][w][lane]; plane 3: packed bases of the segment, [tile][2W+1][lane] */
+/* grid (tile, plane); 64 threads = the tile's lanes; layout [tile][plane][w][lane] */
 __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
                                   const int *__restrict__ seg_seq, const int *__restrict__ seg_s0, int W,
-                                  int L, uint32_t *__restrict__ planes, uint32_t *__restrict__ rowpk)
+                                  int L, uint32_t *__restrict__ planes)
 {
     const int tile = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
     const int s = seg_seq[tile * 64 + lane];
     const int s0 = seg_s0[tile * 64 + lane];
     const int len = s >= 0 ? (int)(off[s + 1] - off[s]) : 0;
     const uint8_t *seq = codes + (s >= 0 ? off[s] : 0);
-    if (plane == 3) {
-        for (int i = 0; i < 2 * W + 1; i++)
-            rowpk[((size_t)tile * (2 * W + 1) + i) * 64 + lane] = s >= 0 ? gkmbs::row_pack_word(seq, len, s0, i) : 0u;
-        return;
-    }
     for (int w = 0; w < W; w++)
         planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] =
             s >= 0 ? gkmbs::row_plane_word(seq, len, s0, w, W, L, plane) : 0u;
@@ -240,14 +226,13 @@ struct GramOut {
 };
 
 struct BsArgs {
-    const uint32_t *rowplanes, *rowpk, *pk;
-    int pkw;
+    const uint32_t *rowplanes;
+    const uint32_t *lmf, *lmr; /* l-mer table entries (l-mer | weight << 24) per strand */
+    const int64_t *lmoff;
     const int *seg_seq, *seg_s0, *seg_slot, *tile_amax;
     const uint32_t *sb;
     int xw;
     const int *len;
-    const uint8_t *wd; /* distance-indexed positional weights, wd_len bytes */
-    int wd_len;
     double c[GKM_MAXD1];
     GramOut out;
     int cj, maxseg;
@@ -271,8 +256,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 constexpr int BS_CAP = 12;    /* hit-queue entries per lane */
-constexpr int BS_RING = 320;  /* wave-wide ring of compacted hit words */
-constexpr int BS_CHUNK = 192; /* words compacted into the ring at a time */
+constexpr int BS_SBUF = 448;  /* wave-wide list of compacted hit words */
 constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
 constexpr int BS_DU = 5;   /* shifts per SB register refill */
 
@@ -290,15 +274,15 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
     using namespace gkmbs;
-    /* LDS per wave: 6 KB queue + 2.5 KB ring + 1.25 KB accumulators = 9.75 KB -> 16 waves per CU.
-     * The read-mostly tables (packed segments/strands, weight table) stay in global memory:
-     * they are a few KB per wave and L1/L2 resident; keeping them out of LDS buys occupancy,
-     * which is what hides the latency of the drain (measured: 301 -> 244 ms on config 2). */
+    /* LDS per wave: 6 KB queue + 3.5 KB list + 1.25 KB accumulators = 10.75 KB -> 14 waves per CU.
+     * The l-mer tables the hit resolution reads stay in global memory (1.2 KB per sequence and
+     * strand, L1/L2 resident); keeping them out of LDS buys occupancy, which is what hides the
+     * latency of the drain (measured: 301 -> 244 ms on config 2). */
     __shared__ uint32_t q_h[BS_CAP * 64];    /* per-lane hit queue: hit word ...                */
     __shared__ uint32_t q_meta[BS_CAP * 64]; /* ... and where it came from (w, delta, strand)   */
-    __shared__ uint32_t s_h[BS_RING];        /* wave-wide ring of compacted hit words ...       */
-    __shared__ uint32_t s_meta[BS_RING];     /* ... with origin incl. the source lane           */
-    __shared__ uint32_t rowinfo[64];         /* s0 | centre << 12 of every lane                 */
+    __shared__ uint32_t s_h[BS_SBUF];        /* wave-wide list of compacted hit words ...       */
+    __shared__ uint32_t s_meta[BS_SBUF];     /* ... with origin incl. the source lane           */
+    __shared__ uint32_t rowbase[64];         /* l-mer table index of every lane's segment start */
     __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]         */
     constexpr int HALF = (W + 1) / 2;        /* the queue is checked twice per shift            */
     static_assert(BS_CAP > HALF + 2, "queue too small for W");
@@ -310,9 +294,6 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int j1 = min(j0 + A.cj, amax + 1);
     if (j0 >= j1) return;
 
-    const uint8_t *wdg = A.wd;
-    const uint32_t *rowpk_g = A.rowpk + (size_t)tile * (2 * W + 1) * 64;
-
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
     for (int w = 0; w < W; w++) {
@@ -323,100 +304,120 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
     const int myseq = A.seg_seq[tile * 64 + lane];
     const int s0 = A.seg_s0[tile * 64 + lane];
     const int slot = A.seg_slot[tile * 64 + lane];
-    const int cA = myseq >= 0 ? (A.len[myseq] - L + 1) / 2 : 0; /* centre l-mer, libgkm.c:912 */
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
-    rowinfo[lane] = (uint32_t)s0 | ((uint32_t)cA << 12);
+    rowbase[lane] = myseq >= 0 ? (uint32_t)(A.lmoff[myseq] + s0) : 0u;
     const uint32_t lane_tag = (uint32_t)lane << 18;
-
-    auto wt_at = [&](int dist) { return (uint32_t)wdg[dist]; };
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
-        const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
-        const int pkw = A.pkw;
-        const uint32_t *colpk_g = A.pk + (size_t)(j * 2) * pkw;
-        auto col_word = [&](int strand, int i) { return colpk_g[strand * pkw + i]; };
+        const uint32_t *colf = A.lmf + A.lmoff[j], *colr = A.lmr + A.lmoff[j];
+        auto col_lmer = [&](int strand, int q) { return strand ? colr[q] : colf[q]; };
 #pragma unroll
         for (int k = 0; k <= D; k++) accl[k * 64 + lane] = 0u;
         int qn = 0;
 
         /* one hit record -> accl[m][source lane] += wa * wb */
         auto resolve = [&](uint32_t rec) {
+            if (VARIANT & 16) { atomicAdd(&accl[rec_lane(rec)], rec); return; } /* timing: no table reads */
             const int r = rec_lane(rec);
-            const uint32_t info = rowinfo[r];
-            auto row_word = [&](int i) { return rowpk_g[i * 64 + r]; };
-            const HitValue hv = resolve_hit<W, L, WEIGHTED>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec),
-                                                            (int)(info & 4095u), (uint32_t)T, rcpT, (int)(info >> 12), nB,
-                                                            row_word, col_word, wt_at);
+            const uint32_t *rowf = A.lmf + rowbase[r];
+            auto row_lmer = [&](int i0) { return rowf[i0]; };
+            const HitValue hv = resolve_hit<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
+                                               rcpT, row_lmer, col_lmer);
             atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
-        /* Compact the per-lane queues of hit words into a wave-wide ring (prefix sum of the queue
-         * lengths over the lanes, on DPP; whole lanes only, as many as fit), then resolve the ring
-         * in FULL trips of 2 x 64 words with every lane busy: each word gives up its lowest hit
-         * bit, what is left of a multi-hit word is appended to the ring again.  Fewer than one
-         * trip's worth of words stays in the ring for the next drain; the last drain of a column
-         * (final) empties it. */
-        int ring_hd = 0, ring_n = 0;
+        /* Compact the per-lane queues of hit words into one wave-wide list: a DPP prefix sum of the
+         * queue lengths gives every lane its slice [excl, excl+qn) of the list, so the copy is a
+         * fully unrolled, address-arithmetic-free burst (whole lanes only, as many as fit).  The
+         * list is then resolved in FULL trips of 2 x 64 words with every lane busy: each word gives
+         * up its lowest hit bit, what is left of a multi-hit word is appended again.  Fewer than
+         * one trip's worth of words is moved to the front and waits for the next drain; the last
+         * drain of a column (final) empties the list. */
+        int s_n = 0; /* words in the list (wave-uniform), < BS_TRIP between drains */
         auto drain = [&](bool final) {
             const int incl = wave_inclusive_scan(qn);
             const int excl = incl - qn;
             const int total = __builtin_amdgcn_readlane(incl, 63);
+            uint32_t hq[BS_CAP], mq[BS_CAP];
+#pragma unroll
+            for (int e = 0; e < BS_CAP; e++) {
+                hq[e] = q_h[e * 64 + lane];
+                mq[e] = q_meta[e * 64 + lane] | lane_tag;
+            }
             int lo = 0;
             do {
-                if (lo < total) { /* invariant here: ring_n < BS_TRIP, so at least one lane fits */
-                    const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + (BS_RING - ring_n));
+                if (lo < total) { /* here s_n < BS_TRIP: room for at least one whole lane */
+                    const int room = BS_SBUF - BS_TRIP - s_n;
+                    const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + room);
                     const unsigned long long pm = __ballot(part);
                     const int last = 63 - __builtin_clzll(pm);
                     const int hi = __builtin_amdgcn_readlane(incl, last);
-                    int p = ring_hd + ring_n + (excl - lo);
-                    p -= (p >= BS_RING) ? BS_RING : 0;
-                    for (int e = 0; __any(part && e < qn); e++) {
-                        if (part && e < qn) {
-                            s_h[p] = q_h[e * 64 + lane];
-                            s_meta[p] = q_meta[e * 64 + lane] | lane_tag;
-                            p++;
-                            p -= (p >= BS_RING) ? BS_RING : 0;
+                    const int mine = part ? qn : 0;
+                    uint32_t *dh = s_h + s_n + (excl - lo), *dm = s_meta + s_n + (excl - lo);
+#pragma unroll
+                    for (int e = 0; e < BS_CAP; e++) {
+                        if (e < mine) {
+                            dh[e] = hq[e];
+                            dm[e] = mq[e];
                         }
                     }
-                    ring_n += hi - lo;
+                    s_n += hi - lo;
                     lo = hi;
                 }
-                while (ring_n >= BS_TRIP || (final && lo >= total && ring_n > 0)) {
-                    const int c = min(ring_n, BS_TRIP);
+                if (VARIANT & 32) s_n = 0; /* timing: compaction only */
+                int hd = 0;
+                while (s_n - hd >= BS_TRIP || (final && lo >= total && s_n - hd > 0)) {
+                    const int c = min(s_n - hd, BS_TRIP);
                     uint32_t left[2], meta[2];
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const int i = k * 64 + lane;
-                        int q = ring_hd + i;
-                        q -= (q >= BS_RING) ? BS_RING : 0;
-                        const uint32_t h = (i < c) ? s_h[q] : 0u;
-                        meta[k] = s_meta[q];
+                        const uint32_t h = (i < c) ? s_h[hd + i] : 0u;
+                        meta[k] = s_meta[min(hd + i, BS_SBUF - 1)];
                         if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
                         left[k] = h & (h - 1u);
                     }
-                    int appended = 0;
+                    hd += c;
 #pragma unroll
                     for (int k = 0; k < 2; k++) {
                         const unsigned long long more = __ballot(left[k] != 0u);
                         if (more) {
-                            int at = ring_hd + ring_n + appended +
-                                     (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                            at -= (at >= BS_RING) ? BS_RING : 0;
-                            at -= (at >= BS_RING) ? BS_RING : 0;
-                            if (left[k] != 0u) {
+                            const int at = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                            if (left[k] != 0u && at < BS_SBUF) {
                                 s_h[at] = left[k];
                                 s_meta[at] = meta[k];
+                            } else if (left[k] != 0u) { /* list full: finish this word here */
+                                uint32_t h = left[k];
+                                while (h) {
+                                    resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
+                                    h &= h - 1u;
+                                }
                             }
-                            appended += (int)__popcll(more);
+                            s_n = min(s_n + (int)__popcll(more), BS_SBUF);
                         }
                     }
-                    ring_hd += c;
-                    ring_hd -= (ring_hd >= BS_RING) ? BS_RING : 0;
-                    ring_n += appended - c;
                 }
+                const int rem = s_n - hd; /* < BS_TRIP <= hd whenever hd > 0: source and target disjoint */
+                if (hd > 0 && rem > 0) {
+                    uint32_t th[2], tm[2];
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        const int i = min(hd + k * 64 + lane, BS_SBUF - 1);
+                        th[k] = s_h[i];
+                        tm[k] = s_meta[i];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; k++) {
+                        if (k * 64 + lane < rem) {
+                            s_h[k * 64 + lane] = th[k];
+                            s_meta[k * 64 + lane] = tm[k];
+                        }
+                    }
+                }
+                s_n = rem;
             } while (lo < total);
             qn = 0;
         };
@@ -504,8 +505,7 @@ struct DirectArgs {
     int nrows;
     const int *len;
     const int64_t *lmoff;
-    const uint32_t *lmf, *lmr;
-    const uint8_t *wd;
+    const uint32_t *lmf, *lmr; /* l-mer | weight << 24 */
     double c[GKM_MAXD1];
     GramOut out;
     int cj, L, d;
@@ -516,7 +516,6 @@ struct DirectArgs {
  * registers, the column strand's packed l-mers streamed as wave-uniform scalars;
  * XOR / fold / popcount per comparison, rare exec-masked accumulate.
  */
-template <bool WEIGHTED>
 __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
 {
     constexpr int R = 8;
@@ -545,21 +544,16 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
             for (int r = 0; r < R; r++) {
                 const bool ok = (p0 + r) < na;
                 u[r] = ok ? A.lmf[offa + p0 + r] : 0u;
-                wu[r] = ok ? (WEIGHTED ? gkmbs::dist_weight(A.wd, na / 2, p0 + r) : 1u) : 0u; /* padding adds 0 */
+                wu[r] = u[r] >> 24; /* padding rows have weight 0 and add nothing */
             }
             for (int qi = 0; qi < nj; qi++) {
                 const uint32_t xf = A.lmf[offj + qi], xr = A.lmr[offj + qi];
-                const uint32_t wf = WEIGHTED ? gkmbs::dist_weight(A.wd, nj / 2, qi) : 1u;
-                const uint32_t wr = WEIGHTED ? gkmbs::dist_weight(A.wd, nj / 2, nj - 1 - qi) : 1u; /* libgkm.c:924 */
+                const uint32_t wf = xf >> 24, wr = xr >> 24;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    uint32_t t = u[r] ^ xf;
-                    t = (t | (t >> 1)) & 0x55555555u;
-                    int m = __popc(t);
+                    int m = gkmbs::lmer_mismatch(u[r], xf);
                     if (m <= d) acc[m][lane] += wu[r] * wf;
-                    t = u[r] ^ xr;
-                    t = (t | (t >> 1)) & 0x55555555u;
-                    m = __popc(t);
+                    m = gkmbs::lmer_mismatch(u[r], xr);
                     if (m <= d) acc[m][lane] += wu[r] * wr;
                 }
             }
@@ -652,7 +646,7 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
     const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
     if (ctx->lmf.ensure(total_lm) || ctx->lmr.ensure(total_lm)) return 4;
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
-                       ctx->lmoff.p, ctx->L, ctx->lmf.p, ctx->lmr.p);
+                       ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmr.p);
     HIPCHK(hipGetLastError());
     ctx->have_lmers = true;
     return 0;
@@ -662,11 +656,9 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 {
     if (ctx->have_sb && ctx->sb_W == W) return 0;
     const int xw = ((ctx->maxlen + W + BS_DU + 15) / 16) * 16;
-    const int pkw = (ctx->maxlen + 15) / 16 + 1;
-    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw) || ctx->pk.ensure((size_t)ctx->n * 2 * (size_t)pkw)) return 4;
-    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 4), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
-                       W, ctx->L, xw, ctx->sb.p, pkw, ctx->pk.p);
-    ctx->pkw = pkw;
+    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw)) return 4;
+    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 3), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
+                       W, ctx->L, xw, ctx->sb.p);
     HIPCHK(hipGetLastError());
     ctx->sb_xw = xw;
     ctx->sb_W = W;
@@ -689,6 +681,8 @@ static bs_kernel_t pick_bitslice(int L, int d, bool weighted)
         if (vi == 2) return k_gram_bitslice<W, 11, 3, true, 2>;
         if (vi == 4) return k_gram_bitslice<W, 11, 3, true, 4>;
         if (vi == 5) return k_gram_bitslice<W, 11, 3, true, 5>;
+        if (vi == 16) return k_gram_bitslice<W, 11, 3, true, 16>;
+        if (vi == 32) return k_gram_bitslice<W, 11, 3, true, 32>;
     }
     GKM_BS(10, 3)
     GKM_BS(11, 3)
@@ -732,7 +726,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     if (bs) {
         const int W = BS_W;
         const int cap = gkmbs::segment_capacity(W, L);
-        if (ensure_sb(ctx, W, stream)) return 4;
+        if (ensure_sb(ctx, W, stream) || ensure_lmers(ctx, stream)) return 4;
         /* lay the rows out as tiles of 64 segments; all segments of one sequence share a tile */
         std::vector<int> seg_seq, seg_s0, seg_slot, tile_amax;
         int maxseg = 1;
@@ -753,23 +747,23 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
             tile_amax[k / 64] = std::max(tile_amax[k / 64], seg_seq[k]);
         if (ctx->seg_seq.ensure(seg_seq.size()) || ctx->seg_s0.ensure(seg_seq.size()) ||
             ctx->seg_slot.ensure(seg_seq.size()) || ctx->tile_amax.ensure((size_t)ntiles) ||
-            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64) || ctx->rowpk.ensure((size_t)ntiles * (2 * W + 1) * 64))
+            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64))
             return 4;
         HIPCHK(hipMemcpyAsync(ctx->seg_seq.p, seg_seq.data(), seg_seq.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->seg_s0.p, seg_s0.data(), seg_s0.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->seg_slot.p, seg_slot.data(), seg_slot.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, tile_amax.data(), tile_amax.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         /* the host vectors above are pageable: the copies have completed on return */
-        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p, ctx->rowpk.p);
+        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
+                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p);
         HIPCHK(hipGetLastError());
 
         BsArgs A;
-        A.rowplanes = ctx->rowplanes.p; A.rowpk = ctx->rowpk.p; A.pk = ctx->pk.p; A.pkw = ctx->pkw;
+        A.rowplanes = ctx->rowplanes.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.lmoff = ctx->lmoff.p;
         A.seg_seq = ctx->seg_seq.p; A.seg_s0 = ctx->seg_s0.p; A.seg_slot = ctx->seg_slot.p;
         A.tile_amax = ctx->tile_amax.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
-        A.len = ctx->len.p; A.wd = ctx->wd.p; A.wd_len = ctx->wd_len;
+        A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 4; /* small work items: better tail balance (sweep: 4 -> 192 ms, 16 -> 197, 64 -> 221) */
@@ -788,15 +782,14 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
         DirectArgs A;
         A.rows = ctx->rows.p; A.nrows = nrows;
-        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.wd = ctx->wd.p;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 16; A.L = L; A.d = d;
         const unsigned ntiles = (unsigned)((nrows + 63) / 64);
         const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
         HIPCHK(hipEventRecord(ctx->ev0, stream));
-        if (ctx->weighted) hipLaunchKernelGGL(k_gram_direct<true>, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
-        else hipLaunchKernelGGL(k_gram_direct<false>, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
+        hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, stream));
         ctx->last_kernel = "k_gram_direct";
