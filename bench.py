@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "bitslice"])
     ap.add_argument("--cpu-sample", type=int, default=1500, help="pos (=neg) sequences of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--check", action="store_true", help="compare the assembled matrix with a 1-GPU run (debug)")
     args = ap.parse_args()
 
     import torch
@@ -124,10 +125,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # Rehearsal knobs (not used by the driver): GKM_BENCH_BACKEND=gloo runs the collective through
+    # host memory, GKM_BENCH_SHARE_GPU=1 puts every rank on GPU 0 -- lets the N>1 path be exercised
+    # on a one-GPU box.
+    backend = os.environ.get("GKM_BENCH_BACKEND", "nccl")
+    if os.environ.get("GKM_BENCH_SHARE_GPU") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     # synthetic problem (identical on every rank), resident in HBM before timing starts
     seqs = [device.encode(s) for s in synth.make_sequences(1, args.n_pos, args.length) +
@@ -152,7 +162,12 @@ def main():
             ctx.gram_rows(rows, full.data_ptr(), n, None, 0, False, stream)
         else:
             ctx.gram_rows(rows, slab.data_ptr(), n, None, 0, True, stream)
-            dist.all_gather_into_tensor(gathered, slab)
+            if backend == "nccl":
+                dist.all_gather_into_tensor(gathered, slab)      # RCCL over xGMI
+            else:
+                host = torch.empty(gathered.shape, dtype=gathered.dtype)
+                dist.all_gather_into_tensor(host, slab.cpu())
+                gathered.copy_(host)
             torch.index_select(gathered, 0, slot_of_row, out=full)
         ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
 
@@ -170,7 +185,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,6 +202,16 @@ def main():
     kern_ms = float(np.mean(durs))
     comparisons = ctx.last_comparisons()       # 2 n_a n_j summed over this rank's (a, j<=a) pairs
     kname = ctx.last_kernel_name()
+
+    if args.check:  # every rank recomputes the whole matrix alone and compares bit for bit
+        ref = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        ctx.gram_rows(np.arange(n), ref.data_ptr(), n, None, 0, False, stream)
+        ctx.normalize(ref.data_ptr(), n, sq.data_ptr(), False, stream)
+        step()
+        torch.cuda.synchronize(dev)
+        same = bool((torch.tril(ref) == torch.tril(full)).all().item())
+        print("rank %d: assembled matrix identical to single-GPU matrix: %s" % (rank, same), file=sys.stderr, flush=True)
+        assert same
 
     pairs = n * (n - 1) / 2
     sec_per_step = elapsed / args.steps
@@ -212,7 +237,9 @@ def main():
     }
     if rank == 0:
         achieved = comparisons * OPS_PER_COMPARISON / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = measured_traffic()
+        traffic, traffic_src = (None, None)
+        if world == 1 and (args.n_pos, args.n_neg, args.length, args.L, args.k, args.d, args.kernel_type) == (5000, 5000, 300, 11, 7, 3, 4):
+            traffic, traffic_src = measured_traffic()   # PMC numbers were taken on exactly this workload
         out["roofline"] = {
             "bound": "valu",
             "achieved": achieved, "peak": PEAK_INT32_GOPS, "unit": "Gop/s", "frac": achieved / PEAK_INT32_GOPS,

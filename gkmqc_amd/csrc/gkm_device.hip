@@ -255,7 +255,6 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     return x;
 }
 
-constexpr int BS_CAP = 12;    /* hit-queue entries per lane */
 constexpr int BS_SBUF = 448;  /* wave-wide list of compacted hit words */
 constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
 constexpr int BS_DU = 5;   /* shifts per SB register refill */
@@ -274,18 +273,16 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
     using namespace gkmbs;
-    /* LDS per wave: 6 KB queue + 3.5 KB list + 1.25 KB accumulators = 10.75 KB -> 14 waves per CU.
-     * The l-mer tables the hit resolution reads stay in global memory (1.2 KB per sequence and
-     * strand, L1/L2 resident); keeping them out of LDS buys occupancy, which is what hides the
-     * latency of the drain (measured: 301 -> 244 ms on config 2). */
-    __shared__ uint32_t q_h[BS_CAP * 64];    /* per-lane hit queue: hit word ...                */
-    __shared__ uint32_t q_meta[BS_CAP * 64]; /* ... and where it came from (w, delta, strand)   */
-    __shared__ uint32_t s_h[BS_SBUF];        /* wave-wide list of compacted hit words ...       */
-    __shared__ uint32_t s_meta[BS_SBUF];     /* ... with origin incl. the source lane           */
-    __shared__ uint32_t rowbase[64];         /* l-mer table index of every lane's segment start */
-    __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]         */
-    constexpr int HALF = (W + 1) / 2;        /* the queue is checked twice per shift            */
-    static_assert(BS_CAP > HALF + 2, "queue too small for W");
+    /* LDS per wave: 3.5 KB hit list + 1.25 KB accumulators + 0.25 KB -> 5 KB, so occupancy is set
+     * by registers.  The l-mer tables the hit resolution reads stay in global memory (1.2 KB per
+     * sequence and strand, L1/L2 resident): keeping LDS small buys the occupancy that hides the
+     * latency of the hit path (measured: 301 -> 244 ms on config 2 when the tables left LDS). */
+    __shared__ uint32_t s_h[BS_SBUF + 1];    /* wave-wide list of hit words (+1 trash slot) ...   */
+    __shared__ uint32_t s_meta[BS_SBUF + 1]; /* ... and their origin: w, delta, strand, row lane  */
+    __shared__ uint32_t rowbase[64];         /* l-mer table index of every lane's segment start   */
+    __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]           */
+    constexpr int HALF = (W + 1) / 2;        /* the list is checked twice per shift               */
+    static_assert(BS_SBUF >= BS_TRIP + 64 * HALF, "hit list too small for W");
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
@@ -315,7 +312,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
         auto col_lmer = [&](int strand, int q) { return strand ? colr[q] : colf[q]; };
 #pragma unroll
         for (int k = 0; k <= D; k++) accl[k * 64 + lane] = 0u;
-        int qn = 0;
+        int s_n = 0; /* words in the hit list (wave-uniform) */
 
         /* one hit record -> accl[m][source lane] += wa * wb */
         auto resolve = [&](uint32_t rec) {
@@ -328,98 +325,63 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
             atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
-        /* Compact the per-lane queues of hit words into one wave-wide list: a DPP prefix sum of the
-         * queue lengths gives every lane its slice [excl, excl+qn) of the list, so the copy is a
-         * fully unrolled, address-arithmetic-free burst (whole lanes only, as many as fit).  The
-         * list is then resolved in FULL trips of 2 x 64 words with every lane busy: each word gives
-         * up its lowest hit bit, what is left of a multi-hit word is appended again.  Fewer than
-         * one trip's worth of words is moved to the front and waits for the next drain; the last
-         * drain of a column (final) empties the list. */
-        int s_n = 0; /* words in the list (wave-uniform), < BS_TRIP between drains */
-        auto drain = [&](bool final) {
-            const int incl = wave_inclusive_scan(qn);
-            const int excl = incl - qn;
-            const int total = __builtin_amdgcn_readlane(incl, 63);
-            uint32_t hq[BS_CAP], mq[BS_CAP];
+        /* Resolve the hit list in FULL trips of 2 x 64 words with every lane busy: each word gives
+         * up its lowest hit bit, what is left of a multi-hit word is appended again.  Fewer than one
+         * trip's worth of words is moved to the front and waits; the last call of a column (final)
+         * empties the list. */
+        auto trips = [&](bool final) {
+            if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
+            int hd = 0;
+            while (s_n - hd >= BS_TRIP || (final && s_n - hd > 0)) {
+                const int c = min(s_n - hd, BS_TRIP);
+                uint32_t left[2], meta[2];
 #pragma unroll
-            for (int e = 0; e < BS_CAP; e++) {
-                hq[e] = q_h[e * 64 + lane];
-                mq[e] = q_meta[e * 64 + lane] | lane_tag;
-            }
-            int lo = 0;
-            do {
-                if (lo < total) { /* here s_n < BS_TRIP: room for at least one whole lane */
-                    const int room = BS_SBUF - BS_TRIP - s_n;
-                    const bool part = (qn > 0) && (excl >= lo) && (incl <= lo + room);
-                    const unsigned long long pm = __ballot(part);
-                    const int last = 63 - __builtin_clzll(pm);
-                    const int hi = __builtin_amdgcn_readlane(incl, last);
-                    const int mine = part ? qn : 0;
-                    uint32_t *dh = s_h + s_n + (excl - lo), *dm = s_meta + s_n + (excl - lo);
-#pragma unroll
-                    for (int e = 0; e < BS_CAP; e++) {
-                        if (e < mine) {
-                            dh[e] = hq[e];
-                            dm[e] = mq[e];
-                        }
-                    }
-                    s_n += hi - lo;
-                    lo = hi;
+                for (int k = 0; k < 2; k++) {
+                    const int i = k * 64 + lane;
+                    const uint32_t h = (i < c) ? s_h[hd + i] : 0u;
+                    meta[k] = s_meta[min(hd + i, BS_SBUF - 1)];
+                    if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
+                    left[k] = h & (h - 1u);
                 }
-                if (VARIANT & 32) s_n = 0; /* timing: compaction only */
-                int hd = 0;
-                while (s_n - hd >= BS_TRIP || (final && lo >= total && s_n - hd > 0)) {
-                    const int c = min(s_n - hd, BS_TRIP);
-                    uint32_t left[2], meta[2];
+                hd += c;
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const int i = k * 64 + lane;
-                        const uint32_t h = (i < c) ? s_h[hd + i] : 0u;
-                        meta[k] = s_meta[min(hd + i, BS_SBUF - 1)];
-                        if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
-                        left[k] = h & (h - 1u);
-                    }
-                    hd += c;
-#pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const unsigned long long more = __ballot(left[k] != 0u);
-                        if (more) {
-                            const int at = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                            if (left[k] != 0u && at < BS_SBUF) {
-                                s_h[at] = left[k];
-                                s_meta[at] = meta[k];
-                            } else if (left[k] != 0u) { /* list full: finish this word here */
-                                uint32_t h = left[k];
-                                while (h) {
-                                    resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
-                                    h &= h - 1u;
-                                }
+                for (int k = 0; k < 2; k++) {
+                    const unsigned long long more = __ballot(left[k] != 0u);
+                    if (more) {
+                        const int at = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                        if (left[k] != 0u && at < BS_SBUF) {
+                            s_h[at] = left[k];
+                            s_meta[at] = meta[k];
+                        } else if (left[k] != 0u) { /* list full: finish this word here */
+                            uint32_t h = left[k];
+                            while (h) {
+                                resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
+                                h &= h - 1u;
                             }
-                            s_n = min(s_n + (int)__popcll(more), BS_SBUF);
                         }
+                        s_n = min(s_n + (int)__popcll(more), BS_SBUF);
                     }
                 }
-                const int rem = s_n - hd; /* < BS_TRIP <= hd whenever hd > 0: source and target disjoint */
-                if (hd > 0 && rem > 0) {
-                    uint32_t th[2], tm[2];
+            }
+            const int rem = s_n - hd; /* < BS_TRIP <= hd whenever hd > 0: source and target disjoint */
+            if (hd > 0 && rem > 0) {
+                uint32_t th[2], tm[2];
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        const int i = min(hd + k * 64 + lane, BS_SBUF - 1);
-                        th[k] = s_h[i];
-                        tm[k] = s_meta[i];
-                    }
+                for (int k = 0; k < 2; k++) {
+                    const int i = min(hd + k * 64 + lane, BS_SBUF - 1);
+                    th[k] = s_h[i];
+                    tm[k] = s_meta[i];
+                }
 #pragma unroll
-                    for (int k = 0; k < 2; k++) {
-                        if (k * 64 + lane < rem) {
-                            s_h[k * 64 + lane] = th[k];
-                            s_meta[k * 64 + lane] = tm[k];
-                        }
+                for (int k = 0; k < 2; k++) {
+                    if (k * 64 + lane < rem) {
+                        s_h[k * 64 + lane] = th[k];
+                        s_meta[k * 64 + lane] = tm[k];
                     }
                 }
-                s_n = rem;
-            } while (lo < total);
-            qn = 0;
+            }
+            s_n = rem;
         };
 
         for (int strand = 0; strand < 2; strand++) {
@@ -442,20 +404,27 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                     if (d0 + u < T) {
                         uint32_t hit[W];
                         window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, bv + u, hit);
+                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand);
 #pragma unroll
                         for (int w = 0; w < W; w++) {
                             const uint32_t h = hit[w];
                             if ((VARIANT & 3) == 1) {
                                 accl[lane] += __popc(h);
                             } else {
-                                /* branch-free push: every lane stores at its own tail, only lanes
-                                 * with a hit advance (a slot without hit is simply overwritten) */
-                                q_h[qn * 64 + lane] = h;
-                                q_meta[qn * 64 + lane] = pack_meta(d0 + u, w, strand);
-                                qn += (h != 0u) ? 1 : 0;
+                                /* wave-level compaction at the source: the lanes with a hit in this
+                                 * word append (word, origin) to the list at tail + their rank among
+                                 * the hit lanes (ballot + mbcnt); the others store to a trash slot,
+                                 * so there is no divergent control flow */
+                                const unsigned long long mask = __ballot(h != 0u);
+                                const int pos = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                const int idx = (h != 0u) ? pos : BS_SBUF;
+                                s_h[idx] = h;
+                                s_meta[idx] = vbase | (uint32_t)w;
+                                s_n += (int)__popcll(mask);
                                 if (w == HALF - 1 || w == W - 1) {
-                                    if ((VARIANT & 3) == 2) { if (__any(qn > BS_CAP - HALF)) qn = 0; }
-                                    else if (__any(qn > BS_CAP - HALF)) drain(false);
+                                    if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
+                                    else if (s_n >= BS_TRIP) trips(false);
                                 }
                             }
                         }
@@ -463,7 +432,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                 }
             }
         }
-        drain(true);
+        trips(true);
 
         uint32_t acc[D + 1];
 #pragma unroll
