@@ -179,6 +179,14 @@ GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
             const uint32_t gt = lop3<tt_gt3(D)>(v.b[2], v.b[1], v.b[0]);
             return V::OV ? (gt | v.ovf) : gt;
         }
+    } else if constexpr (((D + 1) & D) == 0 && D < 8) {
+        /* D + 1 a power of two: "count > D" is the OR of the planes from log2(D+1) up */
+        uint32_t gt;
+        if constexpr (D == 7) gt = v.b[3];
+        else if constexpr (D == 3) gt = v.b[3] | v.b[2];
+        else if constexpr (D == 1) gt = lop3<TT_OR3>(v.b[3], v.b[2], v.b[1]);
+        else gt = lop3<TT_OR3>(v.b[3], v.b[2], v.b[1]) | v.b[0];
+        return V::OV ? (gt | v.ovf) : gt;
     } else {
         uint32_t gt;
         if constexpr (D >= 15) gt = 0u;

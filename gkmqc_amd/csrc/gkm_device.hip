@@ -256,6 +256,7 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 constexpr int BS_SBUF = 448;  /* wave-wide list of compacted hit words */
+constexpr int BS_SPAD = 512;  /* list stride in LDS (>= BS_SBUF + 1 trash slot, multiple of 64) */
 constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
 constexpr int BS_DU = 5;   /* shifts per SB register refill */
 
@@ -273,12 +274,15 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
     using namespace gkmbs;
-    /* LDS per wave: 3.5 KB hit list + 1.25 KB accumulators + 0.25 KB -> 5 KB, so occupancy is set
+    /* LDS per wave: 4 KB hit list + 1.25 KB accumulators + 0.25 KB -> 5.5 KB, so occupancy is set
      * by registers.  The l-mer tables the hit resolution reads stay in global memory (1.2 KB per
      * sequence and strand, L1/L2 resident): keeping LDS small buys the occupancy that hides the
      * latency of the hit path (measured: 301 -> 244 ms on config 2 when the tables left LDS). */
-    __shared__ uint32_t s_h[BS_SBUF + 1];    /* wave-wide list of hit words (+1 trash slot) ...   */
-    __shared__ uint32_t s_meta[BS_SBUF + 1]; /* ... and their origin: w, delta, strand, row lane  */
+    /* one array, meta half exactly 512 dwords after the word half: both stores of a push merge
+     * into a single ds_write2st64_b32 */
+    __shared__ uint32_t s_list[2 * BS_SPAD];
+    uint32_t *const s_h = s_list;              /* wave-wide list of hit words (+ trash slot) ...    */
+    uint32_t *const s_meta = s_list + BS_SPAD; /* ... and their origin: w, delta, strand, row lane  */
     __shared__ uint32_t rowbase[64];         /* l-mer table index of every lane's segment start   */
     __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]           */
     constexpr int HALF = (W + 1) / 2;        /* the list is checked twice per shift               */
@@ -416,11 +420,12 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
                                  * the hit lanes (ballot + mbcnt); the others store to a trash slot,
                                  * so there is no divergent control flow */
                                 const unsigned long long mask = __ballot(h != 0u);
-                                const int pos = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                const int idx = (h != 0u) ? pos : BS_SBUF;
-                                s_h[idx] = h;
-                                s_meta[idx] = vbase | (uint32_t)w;
+                                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                                /* byte offsets so that the address is one v_lshl_add + one select */
+                                const uint32_t at = (h != 0u) ? (((uint32_t)rank << 2) + ((uint32_t)s_n << 2)) : (uint32_t)(BS_SBUF * 4);
+                                *(uint32_t *)((char *)s_h + at) = h;
+                                *(uint32_t *)((char *)s_meta + at) = vbase | (uint32_t)w;
                                 s_n += (int)__popcll(mask);
                                 if (w == HALF - 1 || w == W - 1) {
                                     if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
