@@ -1,0 +1,162 @@
+"""Host-side mirror of the reference's kernel + SVM harness (scripts/gkmsvm.py) for the
+MI355X build -- SURVEY.md §8(f1).
+
+Same names, argument lists and results as the reference so the pipeline can call either:
+
+    computeGkmKernel(args_gkm)            -> (kmat, n_pseqs, n_nseqs)     scripts/gkmsvm.py:67-99
+    crossValidate(args_svm, kmat, np, nn) -> (auc_mean, auc_std)          scripts/gkmsvm.py:127-176
+    init(pos_fa, neg_fa, args)            appends one line to <name>.gkmqc.eval.out   :181-220
+    main()                                same command line               :224-303
+
+Differences (all above the C ABI, none changes a number):
+  * the matrix is produced on the GPU through the device layer (include/gkm_hip.h) and sized to
+    the problem: no 15 000 x 15 000 host buffer to zero-fill, no 15 000-sequence cap;
+  * `np.maximum(kmat, kmat.T)` of the reference (lower triangle against a zero upper triangle,
+    i.e. negative entries clamp to 0) is reproduced exactly, on the device;
+  * `--fast-estimation 1` raises NotImplementedError (the reference hits a NameError there,
+    SURVEY.md App. B #11).
+`computeGkmKernel(..., backend="boundary")` instead drives `gkm_main_pywrapper` exactly like the
+reference does (row pointers into a zeroed matrix) -- useful to validate a drop-in install.
+"""
+import argparse
+import ctypes
+import logging
+import os
+import sys
+from multiprocessing import Pool
+
+import numpy as np
+
+from . import device
+
+_KMAT = None  # shared with forked CV workers, like the reference's module global
+
+
+def computeGkmKernel(args_gkm, backend="device", gpu=0):
+    """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity]."""
+    kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, nproc, verbosity = args_gkm
+    if backend == "boundary":
+        seqs, n_pos, _, _ = device.read_problem(pos_fa, neg_fa)
+        n = len(seqs)
+        kmat = np.zeros((n, n))
+        rows = (kmat.ctypes.data + np.arange(n) * kmat.strides[0]).astype(np.uintp)
+        narr = np.ones(2, dtype=np.int32)
+        opts = device.gkmOpt(kernel_type, L, k, d, int(M), float(H), float(gamma), os.fsencode(pos_fa),
+                             os.fsencode(neg_fa), int(nproc), int(verbosity))
+        ret = device.load().gkm_main_pywrapper(ctypes.byref(opts), rows.ctypes.data, narr.ctypes.data)
+        if ret:
+            logging.error("error on kernel construction")
+            sys.exit()
+        n_pseqs, n_nseqs = int(narr[0]), int(narr[1])
+        return np.maximum(kmat, kmat.T), n_pseqs, n_nseqs
+
+    import torch
+    seqs, n_pos, n_invalid, n_trunc = device.read_problem(pos_fa, neg_fa)
+    if n_pos == 0 or n_pos == len(seqs):
+        logging.error("error on kernel construction")
+        sys.exit()
+    res = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=gpu)
+    K = res["K"]                               # lower triangle + unit diagonal, zeros above
+    K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97
+    return K.cpu().numpy(), n_pos, len(seqs) - n_pos
+
+
+def _svm_fold(job):
+    from sklearn.metrics import roc_auc_score
+    from sklearn.svm import SVC
+    args_svm, y, train, test = job
+    regularization, precision, shrinking, cache_size = args_svm[:4]
+    k_train = _KMAT[train, :][:, train]
+    k_test = _KMAT[test, :][:, train]
+    sv = SVC(kernel="precomputed", C=regularization, tol=precision, shrinking=bool(shrinking), gamma=1.0,
+             cache_size=cache_size)
+    score = sv.fit(k_train, y[train]).decision_function(k_test)
+    auc = roc_auc_score(y[test], score)
+    nu = np.sum(np.abs(sv.dual_coef_[0])) / len(train)
+    logging.info("SVC training and validation; nu = %.3f, AUC = %.3f", nu, auc)
+    return auc
+
+
+def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs):
+    """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p]."""
+    from sklearn.model_selection import StratifiedKFold
+    global _KMAT
+    ncv, repeats, fast_estimation, random_seeds, p = args_svm[4:9]
+    if fast_estimation != 0:
+        raise NotImplementedError("fast AUC estimation is dead code in the reference (its regressor is never loaded)")
+    if random_seeds < 0:
+        random_seeds = None
+    seqids = ["p%4d" % i for i in range(n_pseqs)] + ["n%4d" % i for i in range(n_nseqs)]
+    y = np.concatenate((np.repeat(1, n_pseqs), np.repeat(0, n_nseqs)))
+    jobs = []
+    for _ in range(repeats):
+        folds = StratifiedKFold(n_splits=ncv, shuffle=True, random_state=random_seeds)
+        for train, test in folds.split(seqids, y):
+            jobs.append((args_svm, y, train, test))
+    _KMAT = _kmat
+    try:
+        if p > 1:
+            with Pool(p) as pool:  # forked workers see _KMAT without copying it
+                aucs = pool.map(_svm_fold, jobs)
+        else:
+            aucs = [_svm_fold(j) for j in jobs]
+    finally:
+        _KMAT = None
+    logging.info("done cross-validation.")
+    return (np.mean(aucs), np.std(aucs))
+
+
+def init(pos_fa, neg_fa, args):
+    args_gkm = [args.kernel_type, args.full_word_length, args.non_gap_length, args.max_num_gaps, args.init_decay,
+                args.half_life_decay, args.rbf_gamma, pos_fa, neg_fa, args.n_processes, args.verbosity]
+    logging.info("%s: building up kernel matrix", pos_fa)
+    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm)
+    args_svm = [args.regularization, args.precision, args.shrinking, args.cache_size, args.ncv, args.repeats,
+                args.fast_estimation, args.random_seeds, args.n_processes]
+    logging.info("%s: svm training", pos_fa)
+    auc_score, auc_std = crossValidate(args_svm, kmat, n_pseqs, n_nseqs)
+    logging.info("%s: writing result to output file", pos_fa)
+    with open(args.name + ".gkmqc.eval.out", "a") as fa:
+        fa.write("\t".join(map(str, [pos_fa, neg_fa, n_pseqs, auc_score, auc_std])) + "\n")
+    return auc_score, auc_std
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description="gkm-SVM cross-validation on an MI355X-computed gkm kernel matrix",
+                                     formatter_class=argparse.RawTextHelpFormatter)
+    parser.add_argument("-p", "--pos-fa", type=str, required=True, help="positive fa file. REQUIRED")
+    parser.add_argument("-n", "--neg-fa", type=str, required=True, help="negative fa file. REQUIRED")
+    parser.add_argument("-w", "--name", type=str, required=True, help="prefix of output file to write AUC score. REQUIRED")
+    parser.add_argument("-s", "--random-seeds", type=int, default=-1, help="random seed (default: no seed)")
+    parser.add_argument("-@", "--n-processes", type=int, default=1, help="number of processes (default: 1)")
+    parser.add_argument("-v", "--verbosity", type=int, default=1, help="verbosity (default: 1), 0: silent")
+    g = parser.add_argument_group("gkm-kernel")
+    g.add_argument("-t", "--kernel-type", type=int, default=4,
+                   help="0 gapped-kmer, 1 estimated l-mer full filter, 2 truncated filter (gkm), 3 gkm+RBF,\n"
+                        "4 gkm + centre weighted (wgkm, default), 5 wgkm+RBF")
+    g.add_argument("-L", "--full-word-length", type=int, default=10, help="full word length, 3<=L<=12 (default: 10)")
+    g.add_argument("-k", "--non-gap-length", type=int, default=6, help="non-gap positions, k<=L (default: 6)")
+    g.add_argument("-d", "--max-num-gaps", type=int, default=3, help="max gaps, d<=min(4, L-k) (default: 3)")
+    g.add_argument("-M", "--init-decay", type=int, default=50, help="initial value of the decay, -t 4/5 (default: 50)")
+    g.add_argument("-H", "--half-life-decay", type=int, default=50, help="half life of the decay, -t 4/5 (default: 50)")
+    g.add_argument("-G", "--rbf-gamma", type=float, default=1.0, help="gamma for RBF kernels, -t 3/5 (default: 1.0)")
+    v = parser.add_argument_group("SVM training")
+    v.add_argument("-C", "--regularization", type=float, default=1.0, help="regularization parameter C (default: 1.0)")
+    v.add_argument("-e", "--precision", type=float, default=0.001, help="precision parameter epsilon (default: 0.001)")
+    v.add_argument("-u", "--shrinking", type=int, default=0, help="use the shrinking heuristics (default: 0)")
+    v.add_argument("-c", "--cache-size", type=int, default=512, help="cache memory size in MB (default: 512)")
+    v.add_argument("-x", "--ncv", type=int, default=5, help="x-fold cross validation (default: 5)")
+    v.add_argument("-r", "--repeats", type=int, default=1, help="repeats of CV training (default: 1)")
+    v.add_argument("-f", "--fast-estimation", type=int, default=0, help="not supported (dead code in the reference)")
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    return init(args.pos_fa, args.neg_fa, args)
+
+
+if __name__ == "__main__":
+    logging.basicConfig(stream=sys.stdout, format="%(levelname)s %(asctime)s: %(message)s",
+                        datefmt="%Y-%m-%d %H:%M:%S", level=logging.INFO)
+    main()

@@ -1,0 +1,71 @@
+"""gkmqc_amd/gkmsvm.py (host-side mirror of the reference's scripts/gkmsvm.py) against numbers
+returned by the reference's own module (tests/golden/make_golden_gkmsvm.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+EXPECTED = json.load(open(os.path.join(helpers.GOLDEN, "gkmsvm_expected.json")))
+POS = os.path.join(helpers.GOLDEN, "motif_pos.fa")
+NEG = os.path.join(helpers.GOLDEN, "motif_neg.fa")
+
+
+def _args_gkm(case):
+    a = list(case["args_gkm"])
+    a[7], a[8] = POS, NEG
+    return a
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_cross_validate_matches_reference_on_cpu(built, name):
+    """CV half of the mirror, fed with the oracle's matrix symmetrised the reference's way."""
+    from gkmqc_amd import gkmsvm
+    from oracle import oracle as O
+    case = EXPECTED[name]
+    t, L, k, d, M, H, g = case["args_gkm"][:7]
+    r = O.gram(O.make_opt(t, L, k, d, M, H, g, POS, NEG), want_profiles=False, nthreads=8)
+    kmat = np.maximum(np.tril(r["K"]), np.tril(r["K"]).T)
+    assert (r["n_pos"], r["n"] - r["n_pos"]) == (case["n_pos"], case["n_neg"])
+    got = kmat[case["sample_i"], case["sample_j"]]
+    assert helpers.max_rel_err(got, np.array(case["sample_v"])) < 1e-9
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), kmat, case["n_pos"], case["n_neg"])
+    assert abs(auc - case["auc_mean"]) < 1e-9 and abs(std - case["auc_std"]) < 1e-9
+
+
+def test_fast_estimation_is_rejected(built):
+    from gkmqc_amd import gkmsvm
+    with pytest.raises(NotImplementedError):
+        gkmsvm.crossValidate([1.0, 0.001, 0, 512, 5, 1, 1, 7, 1], np.eye(4), 2, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend", ["device", "boundary"])
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_compute_kernel_and_auc_on_gpu(built, name, backend):
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED[name]
+    kmat, n_pos, n_neg = gkmsvm.computeGkmKernel(_args_gkm(case), backend=backend)
+    assert (n_pos, n_neg) == (case["n_pos"], case["n_neg"])
+    assert kmat.shape == (n_pos + n_neg, n_pos + n_neg) and (kmat == kmat.T).all()
+    tol = 1e-10 if case["args_gkm"][0] in (3, 5) else 1e-12   # RBF types use the device exp()
+    assert helpers.max_rel_err(kmat[case["sample_i"], case["sample_j"]], np.array(case["sample_v"])) < tol
+    assert abs(kmat.min() - case["kmat_min"]) < 1e-12          # type 1: negatives clamp to 0 as in the reference
+    assert abs(kmat.sum() - case["kmat_sum"]) < 1e-9 * abs(case["kmat_sum"])
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), kmat, n_pos, n_neg)
+    assert abs(auc - case["auc_mean"]) < 1e-9 and abs(std - case["auc_std"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_init_writes_the_eval_line(built, tmp_path):
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    out = str(tmp_path / "run1")
+    argv = ["-p", POS, "-n", NEG, "-w", out, "-s", "7", "-@", "2", "-v", "0", "-t", "4", "-L", "10", "-k", "6", "-d", "3",
+            "-r", "2"]
+    auc, std = gkmsvm.main(argv)
+    line = open(out + ".gkmqc.eval.out").read().rstrip("\n").split("\t")
+    assert line[0] == POS and line[1] == NEG and int(line[2]) == case["n_pos"]
+    assert abs(float(line[3]) - case["auc_mean"]) < 1e-9 and abs(float(line[4]) - case["auc_std"]) < 1e-9
