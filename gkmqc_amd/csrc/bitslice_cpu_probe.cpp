@@ -47,14 +47,15 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
         for (int st = 0; st < 2; st++)
             for (int delta = 0; delta < T; delta++) {
                 uint32_t hit[W];
+                /* odd shifts exercise the variant that leaves the column-side validity to resolve_hit */
                 window_hits<W, L, D>(Ahi, Alo, AV, &sb[st][0][(size_t)delta], &sb[st][1][(size_t)delta],
-                                     &sb[st][2][(size_t)delta], hit);
+                                     (delta & 1) ? (const uint32_t *)nullptr : &sb[st][2][(size_t)delta], hit);
                 for (int w = 0; w < W; w++) {
                     uint32_t h = hit[w];
                     while (h) {
                         const int bit = __builtin_ctz(h);
                         h &= h - 1u;
-                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, rl, cl);
+                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, rl, cl);
                         acc[hv.m] += hv.v;
                     }
                 }

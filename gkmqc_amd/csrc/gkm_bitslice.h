@@ -231,8 +231,12 @@ struct PlaneSum {
  *   Ahi/Alo/AV : the segment's planes, W words each (per lane)
  *   Bhi/Blo/Bv : SB words x = delta .. delta+W-1 of the column strand (wave-uniform)
  * For w in [0,W): hit[w] = windows (bit b <-> segment base b*W + w) with <= D mismatches
- * whose start is valid on both sides.  The exact count of a hit is recomputed from the
- * packed l-mers when the hit is consumed (cheaper than carrying the count planes along).
+ * whose start is valid on both sides.  With Bv == nullptr the column-side validity (the
+ * window must not wrap around the end of the strand) is NOT applied here: the ~L/T of
+ * windows concerned then yield a few candidate hits more, which resolve_hit() rejects --
+ * one operand and one scalar-operand instruction less per word in the hot loop.
+ * The exact count of a hit is recomputed from the l-mer tables when the hit is consumed
+ * (cheaper than carrying the count planes along).
  *
  * Window counts: the first window (w = 0) is summed with an adder tree; every further window
  * differs from its left neighbour by one base entering and one leaving, so the exact
@@ -266,7 +270,7 @@ GKM_HD void window_hits(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t
                 if (i + 1 < P) t = lop3<TT_A_AND_BXC>(t, old, zout);
             }
         }
-        hit[w] = lop3<TT_NA_B_C>(cnt_exceeds<D>(cnt), AV[w], Bv[w]);
+        hit[w] = Bv ? lop3<TT_NA_B_C>(cnt_exceeds<D>(cnt), AV[w], Bv[w]) : (~cnt_exceeds<D>(cnt) & AV[w]);
     }
 }
 
@@ -364,7 +368,8 @@ struct HitValue {
     uint32_t v;
 };
 template <int W, class RowLm, class ColLm>
-GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, uint32_t T, uint32_t rcpT, RowLm rowlm, ColLm collm)
+GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, uint32_t T, uint32_t rcpT, int nB, RowLm rowlm,
+                            ColLm collm)
 {
     HitValue r;
     const int i0 = b * W + w;
@@ -375,6 +380,11 @@ GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, uint32_t T, uin
         q = (int)(y < x ? y : x);
     } else {
         q = (int)mod_small(x, T, rcpT);
+    }
+    if (q >= nB) { /* window wraps around the end of the strand: not an l-mer (see window_hits) */
+        r.m = 0;
+        r.v = 0u;
+        return r;
     }
     const uint32_t ea = rowlm(i0), eb = collm(strand, q);
     r.m = lmer_mismatch(ea, eb);

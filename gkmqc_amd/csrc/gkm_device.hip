@@ -196,7 +196,7 @@ __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__r
     const int s = e >> 1, strand = e & 1;
     const uint8_t *seq = codes + off[s];
     const int T = (int)(off[s + 1] - off[s]);
-    uint32_t *dst = sb + ((size_t)e * 3 + plane) * xw;
+    uint32_t *dst = sb + ((size_t)e * 2 + plane) * xw; /* planes: 0 = hi bit, 1 = lo bit of the base code */
     for (int x = threadIdx.x; x < xw; x += blockDim.x)
         dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
 }
@@ -258,7 +258,13 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 constexpr int BS_SBUF = 448;  /* wave-wide list of compacted hit words */
 constexpr int BS_SPAD = 512;  /* list stride in LDS (>= BS_SBUF + 1 trash slot, multiple of 64) */
 constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
-constexpr int BS_DU = 5;   /* shifts per SB register refill */
+#ifndef GKM_BS_DU
+#define GKM_BS_DU 3 /* A/B on config 2: 2 -> 114.9 ms, 3 -> 114.8, 5 -> 118.0, 10 -> 117.9 */
+#endif
+#ifndef GKM_BS_WAVES
+#define GKM_BS_WAVES 1
+#endif
+constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 
 /*
  * One wavefront = 64 row segments (one per lane) x a chunk of `cj` column sequences.
@@ -268,7 +274,7 @@ constexpr int BS_DU = 5;   /* shifts per SB register refill */
  * in batches, so the hot loop has no data-dependent control flow besides the push.
  */
 template <int W, int L, int D, bool WEIGHTED, int VARIANT = 0>
-__global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
@@ -311,6 +317,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
+        const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
         const uint32_t *colf = A.lmf + A.lmoff[j], *colr = A.lmr + A.lmoff[j];
         auto col_lmer = [&](int strand, int q) { return strand ? colr[q] : colf[q]; };
@@ -325,7 +332,7 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
             const uint32_t *rowf = A.lmf + rowbase[r];
             auto row_lmer = [&](int i0) { return rowf[i0]; };
             const HitValue hv = resolve_hit<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
-                                               rcpT, row_lmer, col_lmer);
+                                               rcpT, nB, row_lmer, col_lmer);
             atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
@@ -392,22 +399,22 @@ __global__ __launch_bounds__(64) void k_gram_bitslice(const BsArgs A)
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
             typedef typename std::conditional<(VARIANT & 4) != 0, const uint32_t *, sgpr_words>::type sb_ptr;
-            const sb_ptr sbh = (sb_ptr)(A.sb + ((size_t)(j * 2 + strand) * 3) * A.xw);
+            const sb_ptr sbh = (sb_ptr)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
             const sb_ptr sbl = sbh + A.xw;
-            const sb_ptr sbv = sbl + A.xw;
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
-                uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1], bv[BS_DU + W - 1];
+                /* the strand's window-validity plane (third SB plane) is not streamed: wrapped
+                 * windows are rejected when a hit is resolved (gkm_bitslice.h window_hits) */
+                uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
 #pragma unroll
                 for (int i = 0; i < BS_DU + W - 1; i++) {
                     bh[i] = sbh[d0 + i];
                     bl[i] = sbl[d0 + i];
-                    bv[i] = sbv[d0 + i];
                 }
 #pragma unroll
                 for (int u = 0; u < BS_DU; u++) {
                     if (d0 + u < T) {
                         uint32_t hit[W];
-                        window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, bv + u, hit);
+                        window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, (const uint32_t *)nullptr, hit);
                         const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand);
 #pragma unroll
                         for (int w = 0; w < W; w++) {
@@ -630,8 +637,8 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 {
     if (ctx->have_sb && ctx->sb_W == W) return 0;
     const int xw = ((ctx->maxlen + W + BS_DU + 15) / 16) * 16;
-    if (ctx->sb.ensure((size_t)ctx->n * 2 * 3 * (size_t)xw)) return 4;
-    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 3), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
+    if (ctx->sb.ensure((size_t)ctx->n * 2 * 2 * (size_t)xw)) return 4;
+    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 2), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
                        W, ctx->L, xw, ctx->sb.p);
     HIPCHK(hipGetLastError());
     ctx->sb_xw = xw;

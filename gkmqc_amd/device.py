@@ -39,7 +39,8 @@ _lib = None
 
 
 def lib_path():
-    return os.path.join(LIB_DIR, LIB_NAME)
+    # GKM_LIB_PATH: load another build of the same library (A/B timing of kernel variants)
+    return os.environ.get("GKM_LIB_PATH") or os.path.join(LIB_DIR, LIB_NAME)
 
 
 def load():

@@ -171,3 +171,52 @@ def test_c2_full_size_against_reference_digest(dev):
     assert abs(tri.sum() - float(z["total"])) < 1e-9 * abs(float(z["total"]))
     same = hashlib.sha256(tri.tobytes()).digest() == z["sha256"].tobytes()
     print("C2 full: %s, %.1f ms device, bit-identical to the reference: %s" % (res["kernel"], res["ms"], same))
+
+
+def _oracle_profiles(seqs, t, L, k, d, M=50, H=50.0):
+    from oracle import oracle as O
+    opt = O.make_opt(t, L, k, d, M, H)
+    n = len(seqs)
+    P = np.zeros((n, n, d + 1), dtype=np.int32)
+    prof = np.zeros(d + 1, dtype=np.int32)
+    vp = ctypes.c_void_p
+    for a in range(n):
+        for j in range(a + 1):
+            O.lib().gkmo_profile(ctypes.byref(opt), seqs[a].ctypes.data_as(vp), len(seqs[a]),
+                                 seqs[j].ctypes.data_as(vp), len(seqs[j]), prof.ctypes.data_as(vp))
+            P[a, j] = prof
+    return P
+
+
+def test_dense_hits_and_repeats(dev):
+    """Repeat-like input where almost every window is a hit (the rare path becomes the hot
+    path: multi-hit words, list overflow handling): identical sequences, poly-A, dinucleotide
+    and short-period repeats, next to random ones."""
+    rng = np.random.default_rng(99)
+    base = rng.integers(0, 4, 300).astype(np.uint8)
+    seqs = [base.copy() for _ in range(12)]
+    seqs += [np.zeros(300, np.uint8) for _ in range(8)]                                   # poly-A
+    seqs += [np.tile(np.array([0, 1], np.uint8), 150) for _ in range(6)]                  # (AC)n
+    seqs += [np.tile(np.array([0, 3, 3, 0, 2], np.uint8), 60) for _ in range(6)]          # period 5
+    seqs += [np.full(300, 3, np.uint8) for _ in range(4)]                                 # poly-T (rc of poly-A)
+    seqs += [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(40, 700, 40)]
+    order = rng.permutation(len(seqs))
+    seqs = [seqs[i] for i in order]
+    for (t, L, k, d) in [(4, 11, 7, 3), (2, 10, 6, 3), (4, 12, 8, 4)]:
+        want = _oracle_profiles(seqs, t, L, k, d)
+        il = np.tril_indices(len(seqs))
+        for kern in (dev.KERNEL_BITSLICE, dev.KERNEL_DIRECT):
+            res = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=kern)
+            assert (res["P"].cpu().numpy()[il] == want[il]).all(), (t, L, d, res["kernel"])
+
+
+def test_int32_wraparound_matches_wrapping_arithmetic(dev):
+    """Long sequences with M=255 overflow the reference's int accumulators;
+    the kernels wrap modulo 2^32 exactly like the oracle's unsigned arithmetic."""
+    seqs = [np.zeros(2047, np.uint8), np.zeros(2000, np.uint8), np.tile(np.array([0, 0, 1], np.uint8), 600)]
+    want = _oracle_profiles(seqs, 4, 10, 6, 3, M=255, H=2000.0)
+    assert (want < 0).any() or (np.abs(want.astype(np.int64)) > 2 ** 30).any()
+    il = np.tril_indices(len(seqs))
+    for kern in (dev.KERNEL_BITSLICE, dev.KERNEL_DIRECT):
+        res = dev.gram_matrix(seqs, 4, 10, 6, 3, 255, 2000.0, want_profiles=True, kernel=kern)
+        assert (res["P"].cpu().numpy()[il] == want[il]).all()
