@@ -273,7 +273,7 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * Hit words are parked in a per-lane LDS queue and turned into weighted profile counts
  * in batches, so the hot loop has no data-dependent control flow besides the push.
  */
-template <int W, int L, int D, bool WEIGHTED, int VARIANT = 0>
+template <int W, int L, int D, int VARIANT = 0>
 __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
@@ -651,19 +651,18 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 typedef void (*bs_kernel_t)(const BsArgs);
 
 template <int W>
-static bs_kernel_t pick_bitslice(int L, int d, bool weighted)
+static bs_kernel_t pick_bitslice(int L, int d)
 {
 #define GKM_BS(LL, DD) \
-    if (L == LL && d == DD) return weighted ? k_gram_bitslice<W, LL, DD, true> : k_gram_bitslice<W, LL, DD, false>;
-    if (L == 11 && d == 3 && weighted) {
+    if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD>;
+    if (L == 11 && d == 3) { /* timing experiments (tools/variants.sh); results are wrong for != 0 */
         const char *v = getenv("GKM_VARIANT");
         const int vi = v ? atoi(v) : 0;
-        if (vi == 1) return k_gram_bitslice<W, 11, 3, true, 1>;
-        if (vi == 2) return k_gram_bitslice<W, 11, 3, true, 2>;
-        if (vi == 4) return k_gram_bitslice<W, 11, 3, true, 4>;
-        if (vi == 5) return k_gram_bitslice<W, 11, 3, true, 5>;
-        if (vi == 16) return k_gram_bitslice<W, 11, 3, true, 16>;
-        if (vi == 32) return k_gram_bitslice<W, 11, 3, true, 32>;
+        if (vi == 1) return k_gram_bitslice<W, 11, 3, 1>;
+        if (vi == 2) return k_gram_bitslice<W, 11, 3, 2>;
+        if (vi == 4) return k_gram_bitslice<W, 11, 3, 4>;
+        if (vi == 16) return k_gram_bitslice<W, 11, 3, 16>;
+        if (vi == 32) return k_gram_bitslice<W, 11, 3, 32>;
     }
     GKM_BS(10, 3)
     GKM_BS(11, 3)
@@ -672,6 +671,15 @@ static bs_kernel_t pick_bitslice(int L, int d, bool weighted)
     GKM_BS(9, 4)
     GKM_BS(4, 2)
     GKM_BS(12, 6)
+    GKM_BS(10, 4)
+    GKM_BS(11, 4)
+    GKM_BS(12, 3)
+    GKM_BS(9, 3)
+    GKM_BS(8, 3)
+    GKM_BS(8, 2)
+    GKM_BS(7, 3)
+    GKM_BS(6, 3)
+    GKM_BS(6, 2)
 #undef GKM_BS
     return nullptr;
 }
@@ -700,7 +708,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows;
 
     bs_kernel_t bs = nullptr;
-    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs = pick_bitslice<BS_W>(L, d, ctx->weighted != 0);
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs = pick_bitslice<BS_W>(L, d);
     if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs)
         return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
 

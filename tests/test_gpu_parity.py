@@ -220,3 +220,28 @@ def test_int32_wraparound_matches_wrapping_arithmetic(dev):
     for kern in (dev.KERNEL_BITSLICE, dev.KERNEL_DIRECT):
         res = dev.gram_matrix(seqs, 4, 10, 6, 3, 255, 2000.0, want_profiles=True, kernel=kern)
         assert (res["P"].cpu().numpy()[il] == want[il]).all()
+
+
+@pytest.mark.parametrize("L,d", [(10, 3), (11, 3), (12, 4), (8, 4), (9, 4), (4, 2), (12, 6), (10, 4), (11, 4), (12, 3),
+                                 (9, 3), (8, 3), (8, 2), (7, 3), (6, 3), (6, 2)])
+def test_every_bitslice_instantiation_against_the_general_kernel(dev, L, d):
+    """All (L, d) pairs the bit-sliced kernel is instantiated for, weighted and unweighted, on
+    mixed-length input with multi-segment rows: integer profiles equal to the general kernel's
+    (itself pinned to the reference fixtures) and, on a subset, to the oracle's."""
+    rng = np.random.default_rng(100 * L + d)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(L, 900, 90)]
+    seqs[3] = seqs[7].copy()
+    seqs[11] = (3 - seqs[20][::-1]).astype(np.uint8)      # reverse complement of another sequence
+    k = L - d
+    for t in (2, 4):
+        a = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        b = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+        assert a["kernel"] == "k_gram_bitslice" and b["kernel"] == "k_gram_direct"
+        il = np.tril_indices(len(seqs))
+        Pa, Pb = a["P"].cpu().numpy(), b["P"].cpu().numpy()
+        assert (Pa[il] == Pb[il]).all()
+        assert (a["K"].cpu().numpy() == b["K"].cpu().numpy()).all()
+        sub = seqs[:14]
+        want = _oracle_profiles(sub, t, L, k, d)
+        is_ = np.tril_indices(len(sub))
+        assert (Pa[:14, :14][is_] == want[is_]).all()
