@@ -36,3 +36,29 @@ def gather_index(n, world_size):
         slot_of_row[rows] = g * per + np.arange(len(rows))
     assert (slot_of_row >= 0).all()
     return slot_of_row
+
+
+def chunked_layout(n, world_size, rank, chunks):
+    """Split this rank's rows into `chunks` interleaved sub-lists (row i of the rank's list goes
+    to chunk i % chunks, so every chunk carries the same mix of cheap and expensive rows).  The
+    Gram kernel runs once per chunk and each chunk's slab is all-gathered on its own, which lets
+    the collective of chunk c overlap the kernel of chunk c+1.
+    Returns (list of ascending row arrays, rows_per_chunk)."""
+    rows, _ = folded_rows(n, world_size, rank)
+    per = slab_rows(n, world_size)
+    pc = -(-per // chunks)
+    return [rows[c::chunks] for c in range(chunks)], pc
+
+
+def chunked_gather_index(n, world_size, chunks):
+    """slot_of_row[a] = row index of matrix row a inside the concatenation over chunks c of the
+    all-gathered tensors [world_size * rows_per_chunk, n]."""
+    per = slab_rows(n, world_size)
+    pc = -(-per // chunks)
+    slot_of_row = np.full(n, -1, dtype=np.int64)
+    for g in range(world_size):
+        parts, _ = chunked_layout(n, world_size, g, chunks)
+        for c, r in enumerate(parts):
+            slot_of_row[r] = (c * world_size + g) * pc + np.arange(len(r))
+    assert (slot_of_row >= 0).all()
+    return slot_of_row

@@ -34,6 +34,24 @@ def test_folded_rows_partition_properties():
             assert len(np.unique(slot)) == n
 
 
+def test_chunked_layout_properties():
+    from gkmqc_amd import sharding
+    for n in (5, 63, 400, 10001):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4, 5):
+                slot = sharding.chunked_gather_index(n, world, chunks)
+                assert len(np.unique(slot)) == n
+                seen = np.zeros(n, dtype=int)
+                for r in range(world):
+                    parts, pc = sharding.chunked_layout(n, world, r, chunks)
+                    assert len(parts) == chunks and all(len(p) <= pc for p in parts)
+                    for p in parts:
+                        assert (np.diff(p) > 0).all()
+                        seen[p] += 1
+                assert (seen == 1).all()
+                assert slot.max() < chunks * world * (-(-sharding.slab_rows(n, world) // chunks))
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -49,14 +67,18 @@ def _worker(rank, world, port, raw_path, n, out_path):
     from gkmqc_amd import sharding
     dist.init_process_group("gloo", rank=rank, world_size=world)
     raw = np.load(raw_path)                     # raw G(a, j), lower triangle + diagonal
-    rows, pad = sharding.folded_rows(n, world, rank)
-    per = sharding.slab_rows(n, world)
-    slab = torch.zeros((per, n), dtype=torch.float64)
-    slab[: len(rows)] = torch.from_numpy(raw[rows])          # this rank's rows only
-    gathered = torch.zeros((world * per, n), dtype=torch.float64)
-    dist.all_gather_into_tensor(gathered, slab)
-    slot = torch.from_numpy(sharding.gather_index(n, world))
-    full = torch.index_select(gathered, 0, slot)
+    chunks = 3                                  # same layout functions and call order as bench.py
+    parts, pc = sharding.chunked_layout(n, world, rank, chunks)
+    slab = torch.zeros((chunks, pc, n), dtype=torch.float64)
+    gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64)
+    pending = []
+    for c in range(chunks):
+        slab[c, : len(parts[c])] = torch.from_numpy(raw[parts[c]])   # this rank's rows only
+        pending.append(dist.all_gather_into_tensor(gathered[c], slab[c], async_op=True))
+    for w in pending:
+        w.wait()
+    slot = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks))
+    full = torch.index_select(gathered.view(chunks * world * pc, n), 0, slot)
     if rank == 0:
         np.save(out_path, full.numpy())
     dist.barrier()
