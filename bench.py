@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--n-pos", type=int, default=5000)
     ap.add_argument("--n-neg", type=int, default=5000)
     ap.add_argument("--length", type=int, default=300)
+    ap.add_argument("--length-range", type=int, nargs=2, default=None, help="uniform random lengths (config 5: 150 600)")
     ap.add_argument("--kernel-type", type=int, default=4)
     ap.add_argument("-L", type=int, default=11)
     ap.add_argument("-k", type=int, default=7)
@@ -140,8 +141,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # synthetic problem (identical on every rank), resident in HBM before timing starts
-    seqs = [device.encode(s) for s in synth.make_sequences(1, args.n_pos, args.length) +
-            synth.make_sequences(2, args.n_neg, args.length)]
+    lr = tuple(args.length_range) if args.length_range else None
+    seqs = [device.encode(s) for s in synth.make_sequences(1, args.n_pos, args.length, lr) +
+            synth.make_sequences(2, args.n_neg, args.length, lr)]
     n = len(seqs)
     ctx = device.GramContext(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, local_rank)
     ctx.set_kernel({"auto": 0, "direct": 1, "bitslice": 2}[args.kernel])

@@ -20,6 +20,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -58,6 +60,40 @@ extern "C" int gkmhip_device_count(void)
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+/* Pinned staging for device-to-host copies, kept for the life of the process: the pipeline
+ * calls the boundary once per peak subset (20x per run, bin/gkmqc.py:341-343) and pinning
+ * 2 x 64 MB costs ~30 ms per call otherwise.  gkmhip_release_host_cache() frees it. */
+static std::mutex g_stage_mutex;
+static double *g_stage[2] = {nullptr, nullptr};
+static size_t g_stage_bytes = 0;
+
+static int acquire_staging(size_t want, double **out)
+{
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    if (g_stage_bytes < want) {
+        for (int i = 0; i < 2; i++) {
+            if (g_stage[i]) (void)hipHostFree(g_stage[i]);
+            g_stage[i] = nullptr;
+        }
+        g_stage_bytes = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&g_stage[i], want, hipHostMallocDefault));
+        g_stage_bytes = want;
+    }
+    out[0] = g_stage[0];
+    out[1] = g_stage[1];
+    return 0;
+}
+
+extern "C" void gkmhip_release_host_cache(void)
+{
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    for (int i = 0; i < 2; i++) {
+        if (g_stage[i]) (void)hipHostFree(g_stage[i]);
+        g_stage[i] = nullptr;
+    }
+    g_stage_bytes = 0;
 }
 
 /* ----------------------------------------------------------------- context */
@@ -107,9 +143,6 @@ struct gkmhip_ctx {
     bool ev_valid = false;
     double last_comparisons = 0;
     const char *last_kernel = "none";
-    /* pinned staging for D2H */
-    double *stage[2] = {nullptr, nullptr};
-    size_t stage_bytes = 0;
 };
 
 extern "C" gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, double gamma)
@@ -154,8 +187,6 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    for (int i = 0; i < 2; i++)
-        if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
     delete ctx;
 }
 
@@ -551,20 +582,20 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
 }
 
 /* ------------------------------------------------------------ normalise */
-__global__ void k_sqnorm(const double *__restrict__ G, int64_t ld, int n, double *__restrict__ sq)
+__global__ void k_sqnorm(const double *__restrict__ G, int64_t ld, int r0, int r1, double *__restrict__ sq)
 {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sq[i] = sqrt(G[(int64_t)i * ld + i]); /* libgkm.c:753-758 */
+    const int i = r0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < r1) sq[i] = sqrt(G[(int64_t)i * ld + i]); /* libgkm.c:753-758 */
 }
 
 /* K(a,j) = G(a,j) / (sq_a * sq_j): product first, one division (libgkm.c:1169-1172);
  * RBF types: exp(gamma (K-1)) (:1175-1179); K(a,a) = 1.0 (gkmkern_pylib.c:218-221) */
-__global__ void k_normalize(double *__restrict__ G, int64_t ld, int n, const double *__restrict__ sq,
+__global__ void k_normalize(double *__restrict__ G, int64_t ld, int r0, const double *__restrict__ sq,
                             int rbf, double gamma, int symmetric)
 {
-    const int a = blockIdx.y;
+    const int a = r0 + blockIdx.y;
     const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j > a || j >= n) return;
+    if (j > a) return;
     double v;
     if (j == a) {
         v = 1.0;
@@ -788,23 +819,122 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     return 0;
 }
 
+/* rows r0..r1-1 of a matrix whose rows < r1 hold raw values: needs sqrt(G(j,j)) for j < r1 only,
+ * so row blocks can be normalised (and shipped) in ascending order while later ones compute */
+static int normalize_rows(gkmhip_ctx *ctx, double *G, int64_t ld, int r0, int r1, double *sq, int symmetric,
+                          hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_sqnorm, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, stream, G, ld, r0, r1, sq);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_normalize, dim3((unsigned)((r1 + 255) / 256), (unsigned)(r1 - r0)), dim3(256), 0, stream, G,
+                       ld, r0, sq, ctx->rbf, ctx->gamma, symmetric);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int gkmhip_normalize(gkmhip_ctx *ctx, double *G, int64_t ld, double *sqnorm, int symmetric,
                                 void *stream_)
 {
     if (!ctx || !G || ctx->n <= 0) return set_err_msg("gkmhip_normalize: bad arguments", 2);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(ctx->device));
-    const int n = ctx->n;
     double *sq = sqnorm;
     if (!sq) {
-        if (ctx->sq.ensure((size_t)n)) return 4;
+        if (ctx->sq.ensure((size_t)ctx->n)) return 4;
         sq = ctx->sq.p;
     }
-    hipLaunchKernelGGL(k_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, G, ld, n, sq);
-    HIPCHK(hipGetLastError());
-    hipLaunchKernelGGL(k_normalize, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, G, ld,
-                       n, sq, ctx->rbf, ctx->gamma, symmetric);
-    HIPCHK(hipGetLastError());
+    return normalize_rows(ctx, G, ld, 0, ctx->n, sq, symmetric, stream);
+}
+
+/* Whole matrix into caller-owned host rows (rows[a][0..a]) as a pipeline over row blocks of
+ * about equal work: block k+1 is computed while block k travels device -> pinned staging ->
+ * the caller's (pageable) rows.  G is device scratch of n x ld doubles. */
+extern "C" int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads)
+{
+    if (!ctx || !G || !rows || ctx->n <= 0 || ld < ctx->n) return set_err_msg("gkmhip_gram_to_host_rows: bad arguments", 2);
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    const size_t want = (size_t)64 << 20;
+    double *stage[2];
+    if (acquire_staging(want, stage)) return 4;
+    if (ctx->sq.ensure((size_t)n)) return 4;
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 16) nthreads = 16;
+
+    /* blocks: at most 1/12 of the triangle's area each, and a staging rectangle that fits */
+    struct Blk { int r0, r1; };
+    std::vector<Blk> blocks;
+    const double area_cap = (double)n * n / 24.0;
+    for (int r0 = 0; r0 < n;) {
+        int r1 = r0 + 1;
+        while (r1 < n && (size_t)(r1 + 1) * (size_t)(r1 + 1 - r0) * 8 <= want &&
+               ((double)(r1 + 1) * (r1 + 1) - (double)r0 * r0) / 2.0 <= area_cap)
+            r1++;
+        blocks.push_back({r0, r1});
+        r0 = r1;
+    }
+    const size_t B = blocks.size();
+    const bool trace = getenv("GKM_TRACE") != nullptr;
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double t0 = now();
+    double t_wait = 0, t_scatter = 0;
+    hipStream_t sc = nullptr, sd = nullptr;
+    HIPCHK(hipStreamCreate(&sc));
+    HIPCHK(hipStreamCreate(&sd));
+    std::vector<hipEvent_t> done(B, nullptr);
+    int rc = 0;
+    std::vector<int> idx;
+    for (size_t b = 0; b < B && !rc; b++) { /* enqueue all the compute up front */
+        idx.resize((size_t)(blocks[b].r1 - blocks[b].r0));
+        for (size_t i = 0; i < idx.size(); i++) idx[i] = blocks[b].r0 + (int)i;
+        rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sc);
+        if (!rc) rc = normalize_rows(ctx, G, ld, blocks[b].r0, blocks[b].r1, ctx->sq.p, 0, sc);
+        if (!rc && hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) rc = 4;
+        if (!rc && hipEventRecord(done[b], sc) != hipSuccess) rc = 4;
+    }
+    auto issue = [&](size_t b) -> hipError_t {
+        const Blk &k = blocks[b];
+        hipError_t e = hipStreamWaitEvent(sd, done[b], 0);
+        if (e != hipSuccess) return e;
+        return hipMemcpy2DAsync(stage[b & 1], (size_t)k.r1 * 8, G + (size_t)k.r0 * ld, (size_t)ld * 8,
+                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sd);
+    };
+    const double t_enq = now();
+    hipError_t e = rc ? hipErrorUnknown : issue(0);
+    for (size_t b = 0; e == hipSuccess && b < B; b++) {
+        const double tw = now();
+        e = hipStreamSynchronize(sd); /* block b is in stage[b & 1] */
+        if (e != hipSuccess) break;
+        if (b + 1 < B) e = issue(b + 1);
+        t_wait += now() - tw;
+        const double ts = now();
+        const Blk &k = blocks[b];
+        const double *src = stage[b & 1];
+        auto work = [&](int t) {
+            for (int r = k.r0 + t; r < k.r1; r += nthreads)
+                memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));
+        };
+        if (nthreads == 1 || k.r1 - k.r0 < 64) {
+            for (int t = 0; t < nthreads; t++) work(t);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        t_scatter += now() - ts;
+    }
+    (void)hipStreamSynchronize(sc);
+    (void)hipStreamSynchronize(sd);
+    if (trace)
+        fprintf(stderr, "gkmhip_gram_to_host_rows: %zu blocks, setup+enqueue %.1f ms, waiting for blocks %.1f ms, host scatter %.1f ms, total %.1f ms\n",
+                B, t_enq - t0, t_wait, t_scatter, now() - t0);
+    for (auto ev : done)
+        if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(sc);
+    (void)hipStreamDestroy(sd);
+    if (rc) return rc;
+    if (e != hipSuccess) return set_err("gkmhip_gram_to_host_rows", e, __FILE__, __LINE__);
     return 0;
 }
 
@@ -843,14 +973,8 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
     if (!ctx || !K || !rows || n <= 0) return set_err_msg("gkmhip_copy_lower_to_rows: bad arguments", 2);
     HIPCHK(hipSetDevice(ctx->device));
     const size_t want = (size_t)64 << 20;
-    if (ctx->stage_bytes < want) {
-        for (int i = 0; i < 2; i++) {
-            if (ctx->stage[i]) (void)hipHostFree(ctx->stage[i]);
-            ctx->stage[i] = nullptr;
-            HIPCHK(hipHostMalloc((void **)&ctx->stage[i], want, hipHostMallocDefault));
-        }
-        ctx->stage_bytes = want;
-    }
+    double *stage[2];
+    if (acquire_staging(want, stage)) return 4;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
     hipStream_t s;
@@ -866,7 +990,7 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
     }
     auto issue = [&](size_t b) -> hipError_t {
         const Blk &k = blocks[b];
-        return hipMemcpy2DAsync(ctx->stage[b & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
+        return hipMemcpy2DAsync(stage[b & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
                                 (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, s);
     };
     hipError_t e = issue(0);
@@ -875,7 +999,7 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
         if (e != hipSuccess) break;
         if (b + 1 < blocks.size()) e = issue(b + 1);
         const Blk &k = blocks[b];
-        const double *src = ctx->stage[b & 1];
+        const double *src = stage[b & 1];
         auto work = [&](int t) {
             for (int r = k.r0 + t; r < k.r1; r += nthreads)
                 memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));

@@ -208,15 +208,17 @@ static int problem_reserve(gkm_problem *p, int64_t extra)
     return 0;
 }
 
-static inline uint8_t base_code(unsigned char ch, long *invalid)
+/* base codes by table: 0..3 for ACGT in either case; 4 marks "anything else", which counts as
+ * 'A' like in the reference (libgkm.c:864-875) and is tallied for the warning */
+static uint8_t g_code[256];
+static void init_code_table(void)
 {
-    switch (ch) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: ++*invalid; return 0; /* anything else counts as 'A' (libgkm.c:870-873) */
-    }
+    if (g_code[(unsigned char)'T'] == 3) return;
+    for (int i = 0; i < 256; i++) g_code[i] = 4;
+    g_code[(unsigned char)'A'] = g_code[(unsigned char)'a'] = 0;
+    g_code[(unsigned char)'C'] = g_code[(unsigned char)'c'] = 1;
+    g_code[(unsigned char)'G'] = g_code[(unsigned char)'g'] = 2;
+    g_code[(unsigned char)'T'] = g_code[(unsigned char)'t'] = 3;
 }
 
 /* Single linear pass over the mapped file.  Record rules of libgkm.c:1251-1314:
@@ -237,6 +239,7 @@ static int parse_fasta(const char *path, gkm_problem *p)
     }
     close(fd);
 
+    init_code_table();
     int open_record = 0, cur = 0;
     size_t pos = 0;
     while (pos < size) {
@@ -256,8 +259,14 @@ static int parse_fasta(const char *path, gkm_problem *p)
                 take = (size_t)(GKM_MAX_SEQ - cur);
                 p->truncated++;
             }
-            for (size_t i = 0; i < take; i++)
-                p->codes[p->used + (int64_t)i] = base_code((unsigned char)buf[pos + i], &p->invalid);
+            uint8_t *dst = p->codes + p->used;
+            long bad = 0;
+            for (size_t i = 0; i < take; i++) {
+                const uint8_t c = g_code[(unsigned char)buf[pos + i]];
+                bad += c >> 2;
+                dst[i] = c & 3;
+            }
+            p->invalid += bad;
             p->used += (int64_t)take;
             cur += (int)take;
         }

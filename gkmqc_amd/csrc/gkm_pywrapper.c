@@ -29,7 +29,6 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     gkmhip_ctx *ctx = NULL;
     double *dG = NULL;
     uint8_t *wd = NULL;
-    int *rows = NULL;
     const double t_start = now_ms();
 
     if (!opts || !kmat || !kmat_size) return 1;
@@ -123,6 +122,7 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     const char *env = getenv("GKM_DEVICE");
     if (env) device = atoi(env);
     ctx = gkmhip_create(device, L, d, c, rbf, opts->gamma);
+    const double t_created = now_ms();
     if (!ctx) {
         gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
         goto done;
@@ -131,39 +131,33 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         gkm_log(GKM_LOG_ERROR, "device upload failed: %s", gkmhip_last_error());
         goto done;
     }
+    const double t_uploaded = now_ms();
     dG = (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
+    const double t_alloc = now_ms();
     if (!dG) {
         gkm_log(GKM_LOG_ERROR, "device allocation of the %d x %d matrix failed: %s", n, n, gkmhip_last_error());
         goto done;
     }
-    rows = (int *)malloc(sizeof(int) * (size_t)n);
-    if (!rows) goto done;
-    for (int i = 0; i < n; i++) rows[i] = i;
-    if (gkmhip_gram_rows(ctx, rows, n, 0, dG, n, NULL, 0, NULL) || gkmhip_normalize(ctx, dG, n, NULL, 0, NULL) ||
-        gkmhip_sync(NULL)) {
+    /* rows a: K(a, 0..a-1) and the unit diagonal -- exactly the cells the reference writes;
+     * computed, normalised and shipped block by block (compute overlaps the PCIe transfer) */
+    if (gkmhip_gram_to_host_rows(ctx, dG, n, kmat, opts->nthreads > 0 ? opts->nthreads : 1)) {
         gkm_log(GKM_LOG_ERROR, "gram kernel failed: %s", gkmhip_last_error());
         goto done;
     }
     const double t_kernel = now_ms();
-    gkm_log(GKM_LOG_DEBUG, "%s: %.3f ms on device for %.4g l-mer comparisons", gkmhip_last_kernel_name(ctx),
-            gkmhip_last_kernel_ms(ctx), gkmhip_last_comparisons(ctx));
-
-    /* rows a: K(a, 0..a-1) and the unit diagonal -- exactly the cells the reference writes */
-    if (gkmhip_copy_lower_to_rows(ctx, dG, n, n, kmat, opts->nthreads > 0 ? opts->nthreads : 1)) {
-        gkm_log(GKM_LOG_ERROR, "device to host copy failed: %s", gkmhip_last_error());
-        goto done;
-    }
     kmat_size[0] = n_pos;
     kmat_size[1] = n - n_pos;
     rc = 0;
-    gkm_log(GKM_LOG_DEBUG, "timing: read+tables %.1f ms, device %.1f ms, copy-out %.1f ms", t_parsed - t_start,
-            t_kernel - t_parsed, now_ms() - t_kernel);
+    gkm_log(GKM_LOG_DEBUG, "timing: read+tables %.1f ms, context %.1f ms, upload %.1f ms, device malloc %.1f ms, "
+            "gram + copy-out pipeline %.1f ms (kernel %s)", t_parsed - t_start, t_created - t_parsed,
+            t_uploaded - t_created, t_alloc - t_uploaded, t_kernel - t_alloc, gkmhip_last_kernel_name(ctx));
 
-done:
-    free(rows);
+done:;
+    const double t_done = now_ms();
     if (dG) gkmhip_free(dG);
     if (ctx) gkmhip_destroy(ctx);
     free(wd);
     gkm_problem_free(prob);
+    gkm_log(GKM_LOG_DEBUG, "timing: teardown %.1f ms, whole call %.1f ms", now_ms() - t_done, now_ms() - t_start);
     return rc;
 }

@@ -103,6 +103,8 @@ def load():
     L.gkmhip_sync.argtypes = (vp,)
     L.gkmhip_copy_lower_to_rows.restype = i32
     L.gkmhip_copy_lower_to_rows.argtypes = (vp, vp, i64, i32, vp, i32)
+    L.gkmhip_gram_to_host_rows.restype = i32
+    L.gkmhip_gram_to_host_rows.argtypes = (vp, vp, i64, vp, i32)
     L.gkmhip_last_kernel_ms.restype = dbl
     L.gkmhip_last_kernel_ms.argtypes = (vp,)
     L.gkmhip_last_comparisons.restype = dbl

@@ -87,6 +87,16 @@ int gkmhip_sync(void *stream);
 int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64_t ld, int n,
                               double **rows, int nthreads);
 
+/* Whole Gram matrix straight into caller-owned host rows (rows[a][0..a] = K(a, 0..a-1), 1.0):
+ * gram + normalise + device-to-host as a pipeline over row blocks of about equal work, so that
+ * the PCIe transfer and the host-side scatter of one block overlap the kernel of the next.
+ * G: device scratch of n x ld doubles.  This is what gkm_main_pywrapper uses. */
+int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads);
+
+/* The pinned staging buffers of the copy-out calls (2 x 64 MB) are kept for the life of the
+ * process; this releases them (optional). */
+void gkmhip_release_host_cache(void);
+
 /* elapsed milliseconds of the device work of the most recent gkmhip_gram_rows call
  * (HIP events recorded on its stream around the dominant kernel); <0 if unavailable */
 double gkmhip_last_kernel_ms(gkmhip_ctx *ctx);

@@ -51,7 +51,7 @@ for rep in range(2):   # first call pays HIP context creation
     rowp = (kmat.ctypes.data + np.arange(rows_alloc) * kmat.strides[0]).astype(np.uintp)
     sizes = np.ones(2, dtype=np.int32)
     t1 = time.time()
-    opt = device.gkmOpt(args.t, args.L, args.k, args.d, 50, 50.0, 1.0, pf.encode(), nf.encode(), args.threads, 0)
+    opt = device.gkmOpt(args.t, args.L, args.k, args.d, 50, 50.0, 1.0, pf.encode(), nf.encode(), args.threads, int(os.environ.get("GKM_E2E_VERBOSITY", "0")))
     rc = lib.gkm_main_pywrapper(ctypes.byref(opt), rowp.ctypes.data, sizes.ctypes.data)
     t2 = time.time()
     assert rc == 0
