@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "gkm_bitslice.h"
+#include "gkm_pack.h"
 
 using namespace gkmbs;
 
@@ -78,4 +79,125 @@ extern "C" int bsprobe_profile(int W, int L, int d, const uint8_t *A, int lenA, 
     if (!ok) return 1;
     for (int m = 0; m <= d; m++) P[m] = (int32_t)acc[m];
     return 0;
+}
+
+/* ---- packed lanes: several row sequences against one column sequence ------------------------
+ * Packs the rows with gkmpack::pack_rows, checks the packing invariants, builds every lane's
+ * planes from its pieces, runs the lane program and attributes each hit to its piece's row.
+ * P_out[i*(d+1)+m] for row i.  Returns 0, or a negative code naming the violated invariant. */
+template <int W, int L, int D>
+static int run_packed(const uint8_t *codes, const int64_t *off, const int *rows, int nrows, int col,
+                      const uint8_t *wd, int32_t *P_out, int *lanes_used)
+{
+    using namespace gkmpack;
+    std::vector<int> nwin((size_t)nrows);
+    for (int i = 0; i < nrows; i++) nwin[(size_t)i] = (int)(off[rows[i] + 1] - off[rows[i]]) - L + 1;
+    const Packing P = pack_rows(rows, nwin.data(), nrows, W, L);
+    *lanes_used = (int)P.lanes_used;
+    /* invariants: every window of every row owned exactly once; pieces inside their lane; all
+     * pieces of a row in one tile; limits respected */
+    std::vector<std::vector<int>> owned((size_t)nrows);
+    for (int i = 0; i < nrows; i++) owned[(size_t)i].assign((size_t)nwin[(size_t)i], 0);
+    std::vector<int> row_tile((size_t)nrows, -1);
+    std::vector<int> lane_bits((size_t)P.ntiles * LANES, 0), lane_np((size_t)P.ntiles * LANES, 0);
+    for (const Piece &pc : P.pieces) {
+        if (pc.b0 < 0 || pc.nb <= 0 || pc.b0 + pc.nb > 32) return -1;
+        if (pc.cnt <= 0 || pc.cnt > pc.nb * W - (L - 1)) return -2;
+        if (pc.b0 != lane_bits[(size_t)pc.lane]) return -3; /* contiguous, in order */
+        lane_bits[(size_t)pc.lane] += pc.nb;
+        if (++lane_np[(size_t)pc.lane] > MAX_PIECES) return -4;
+        const int t = pc.lane / LANES;
+        const int i = P.tile_out[(size_t)t * MAX_ROWS + pc.slot];
+        if (i < 0 || i >= nrows || rows[i] != pc.row || P.tile_row[(size_t)t * MAX_ROWS + pc.slot] != pc.row) return -5;
+        if (row_tile[(size_t)i] >= 0 && row_tile[(size_t)i] != t) return -6;
+        row_tile[(size_t)i] = t;
+        for (int k = 0; k < pc.cnt; k++) {
+            if (pc.p0 + k >= nwin[(size_t)i]) return -7;
+            owned[(size_t)i][(size_t)(pc.p0 + k)]++;
+        }
+    }
+    for (int i = 0; i < nrows; i++)
+        for (int v : owned[(size_t)i])
+            if (v != 1) return -8;
+    for (int t = 0; t < P.ntiles; t++)
+        if (P.tile_nrows[(size_t)t] > MAX_ROWS) return -9;
+
+    /* the computation */
+    constexpr int NB = planes_for(D);
+    (void)NB;
+    const uint8_t *B = codes + off[col];
+    const int T = (int)(off[col + 1] - off[col]), nB = T - L + 1;
+    std::vector<uint32_t> sb[2][2];
+    for (int st = 0; st < 2; st++)
+        for (int pl = 0; pl < 2; pl++) {
+            sb[st][pl].resize((size_t)T + W);
+            for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
+        }
+    auto weight = [&](int n, int p) { return wd ? (uint32_t)wd[n / 2 > p ? n / 2 - p : p - n / 2] : 1u; };
+    std::vector<uint32_t> lmB[2];
+    for (int st = 0; st < 2; st++) {
+        lmB[st].resize((size_t)nB);
+        for (int q = 0; q < nB; q++) lmB[st][(size_t)q] = lmer_entry(B, T, L, st, q, weight(nB, st ? nB - 1 - q : q));
+    }
+    const uint32_t rcpT = mod_magic((uint32_t)T);
+    std::vector<uint32_t> acc((size_t)nrows * (D + 1), 0u);
+    size_t pi = 0;
+    while (pi < P.pieces.size()) {
+        size_t pj = pi;
+        while (pj < P.pieces.size() && P.pieces[pj].lane == P.pieces[pi].lane) pj++;
+        uint32_t Ahi[W], Alo[W], AV[W], start_mask = 0u;
+        for (int w = 0; w < W; w++) Ahi[w] = Alo[w] = AV[w] = 0u;
+        for (size_t k = pi; k < pj; k++) {
+            const Piece &pc = P.pieces[k];
+            start_mask |= 1u << pc.b0;
+            const uint8_t *seq = codes + off[pc.row];
+            const int len = (int)(off[pc.row + 1] - off[pc.row]);
+            for (int w = 0; w < W; w++)
+                for (int b = 0; b < 32; b++) {
+                    Ahi[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 0) << b;
+                    Alo[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 1) << b;
+                    AV[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 2) << b;
+                }
+        }
+        for (int st = 0; st < 2; st++)
+            for (int delta = 0; delta < T; delta++) {
+                uint32_t hit[W];
+                window_hits<W, L, D>(Ahi, Alo, AV, &sb[st][0][(size_t)delta], &sb[st][1][(size_t)delta],
+                                     (const uint32_t *)nullptr, hit);
+                for (int w = 0; w < W; w++) {
+                    uint32_t h = hit[w];
+                    while (h) {
+                        const int bit = __builtin_ctz(h);
+                        h &= h - 1u;
+                        const Piece &pc = P.pieces[pi + (size_t)piece_of_bitrow(start_mask, bit)];
+                        const uint8_t *seq = codes + off[pc.row];
+                        const int len = (int)(off[pc.row + 1] - off[pc.row]), nA = len - L + 1;
+                        /* the device reads lmf[lmbase + i0] with lmbase = lmoff[row] + p0 - b0*W */
+                        auto rl = [&](int i0) {
+                            const int p = pc.p0 + i0 - pc.b0 * W;
+                            return lmer_entry(seq, len, L, 0, p, weight(nA, p));
+                        };
+                        auto cl = [&](int s2, int q) { return lmB[s2][(size_t)q]; };
+                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, rl, cl);
+                        const int i = P.tile_out[(size_t)(pc.lane / LANES) * MAX_ROWS + pc.slot];
+                        if (hv.m <= D) acc[(size_t)i * (D + 1) + hv.m] += hv.v;
+                        else if (hv.v != 0u) return -20; /* a true hit can never exceed D */
+                    }
+                }
+            }
+        pi = pj;
+    }
+    for (size_t k = 0; k < acc.size(); k++) P_out[k] = (int32_t)acc[k];
+    return 0;
+}
+
+#define PCASE(WW, LL, DD) \
+    if (W == WW && L == LL && d == DD) return run_packed<WW, LL, DD>(codes, off, rows, nrows, col, wd, P, lanes_used);
+
+extern "C" int bsprobe_profile_packed(int W, int L, int d, const uint8_t *codes, const int64_t *off, const int *rows,
+                                      int nrows, int col, const uint8_t *wd, int32_t *P, int *lanes_used)
+{
+    PCASE(10, 11, 3) PCASE(20, 11, 3) PCASE(10, 12, 4) PCASE(20, 12, 4) PCASE(20, 10, 3) PCASE(10, 6, 2) PCASE(20, 6, 2)
+    PCASE(5, 11, 3)
+    return 1;
 }

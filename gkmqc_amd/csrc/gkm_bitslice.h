@@ -107,12 +107,12 @@ GKM_HD void add_plane(const Cnt<NB, M1> &x, const Cnt<NB, M2> &y, uint32_t &c, C
             r.b[I] = lop3<TT_XOR3>(xi, yi, ci);
             if constexpr (want_c) c = lop3<TT_MAJ>(xi, yi, ci);
         } else if constexpr (nin == 2) {
-            const uint32_t u = hx ? x.b[I] : y.b[I];
-            const uint32_t v = hc ? c : y.b[I];
+            const uint32_t u = hx ? x.b[hx ? I : 0] : y.b[hy ? I : 0];
+            const uint32_t v = hc ? c : y.b[hy ? I : 0];
             r.b[I] = u ^ v;
             if constexpr (want_c) c = u & v;
         } else if constexpr (nin == 1) {
-            r.b[I] = hx ? x.b[I] : (hy ? y.b[I] : c);
+            r.b[I] = hx ? x.b[hx ? I : 0] : (hy ? y.b[hy ? I : 0] : c);
         } else {
             r.b[I] = 0u;
         }
@@ -291,6 +291,26 @@ GKM_HD uint32_t row_plane_word(const uint8_t *codes, int len, int s0, int w, int
         v |= bit << b;
     }
     return v;
+}
+
+/* Packed lanes (gkm_pack.h): the bit that one PIECE -- bit rows [b0, b0+nb) of a lane holding
+ * sequence positions p0.. with cnt owned window starts -- contributes to bit row b, word w of
+ * plane 0/1 (hi/lo bit of the base code, 0 beyond the sequence) or plane 2 (window start owned
+ * by the piece).  Bit rows outside the piece contribute 0. */
+GKM_HD uint32_t piece_bit(const uint8_t *codes, int len, int b0, int nb, int p0, int cnt, int b, int w, int W,
+                          int plane)
+{
+    if (b < b0 || b >= b0 + nb) return 0u;
+    const int li = (b - b0) * W + w;
+    if (plane == 2) return li < cnt ? 1u : 0u;
+    const int pos = p0 + li;
+    return pos < len ? ((uint32_t)(codes[pos] >> (1 - plane)) & 1u) : 0u;
+}
+/* piece k of a lane owns bit row b: k = (number of piece starts at or below b) - 1, from the
+ * lane's mask of piece-start bit rows */
+GKM_HD int piece_of_bitrow(uint32_t start_mask, int b)
+{
+    return __builtin_popcount(start_mask & (0xFFFFFFFFu >> (31 - b))) - 1;
 }
 
 /* Word x of a COLUMN STRAND table ("SB"): bit b describes strand base (b*W + x) mod T,

@@ -29,6 +29,7 @@
 
 #include "../../include/gkm_hip.h"
 #include "gkm_bitslice.h"
+#include "gkm_pack.h"
 
 #define GKM_MAXD1 13 /* d <= 12 */
 
@@ -136,8 +137,8 @@ struct gkmhip_ctx {
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch */
-    DevBuf<int> rows, seg_seq, seg_s0, seg_slot, tile_amax;
-    DevBuf<uint32_t> rowplanes;
+    DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_amax;
+    DevBuf<uint32_t> rowplanes, lane_mask, lane_piece;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -183,8 +184,9 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipDeviceSynchronize();
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
-    ctx->rows.release(); ctx->seg_seq.release(); ctx->seg_s0.release(); ctx->seg_slot.release();
-    ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->sq.release();
+    ctx->rows.release(); ctx->piece_desc.release(); ctx->tile_row.release(); ctx->tile_out.release();
+    ctx->tile_nrows.release(); ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->lane_mask.release();
+    ctx->lane_piece.release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -232,19 +234,24 @@ __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__r
         dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
 }
 
-/* grid (tile, plane); 64 threads = the tile's lanes; layout [tile][plane][w][lane] */
+/* Packed lanes (gkm_pack.h): grid (tile, plane); 64 threads = the tile's lanes; output layout
+ * [tile][plane][w][lane].  desc holds MAX_PIECES x {row, b0, nb, p0, cnt} per lane (nb = 0: unused). */
 __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
-                                  const int *__restrict__ seg_seq, const int *__restrict__ seg_s0, int W,
-                                  int L, uint32_t *__restrict__ planes)
+                                  const int *__restrict__ desc, int W, uint32_t *__restrict__ planes)
 {
     const int tile = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
-    const int s = seg_seq[tile * 64 + lane];
-    const int s0 = seg_s0[tile * 64 + lane];
-    const int len = s >= 0 ? (int)(off[s + 1] - off[s]) : 0;
-    const uint8_t *seq = codes + (s >= 0 ? off[s] : 0);
-    for (int w = 0; w < W; w++)
-        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] =
-            s >= 0 ? gkmbs::row_plane_word(seq, len, s0, w, W, L, plane) : 0u;
+    const int *d = desc + (size_t)(tile * 64 + lane) * gkmpack::MAX_PIECES * 5;
+    for (int w = 0; w < W; w++) {
+        uint32_t v = 0u;
+        for (int k = 0; k < gkmpack::MAX_PIECES; k++) {
+            const int row = d[k * 5 + 0], b0 = d[k * 5 + 1], nb = d[k * 5 + 2], p0 = d[k * 5 + 3], cnt = d[k * 5 + 4];
+            if (nb <= 0) continue;
+            const uint8_t *seq = codes + off[row];
+            const int len = (int)(off[row + 1] - off[row]);
+            for (int b = b0; b < b0 + nb; b++) v |= gkmbs::piece_bit(seq, len, b0, nb, p0, cnt, b, w, W, plane) << b;
+        }
+        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] = v;
+    }
 }
 
 /* ------------------------------------------------------------ hot kernels */
@@ -257,19 +264,21 @@ struct GramOut {
 };
 
 struct BsArgs {
-    const uint32_t *rowplanes;
-    const uint32_t *lmf, *lmr; /* l-mer table entries (l-mer | weight << 24) per strand */
+    const uint32_t *rowplanes;  /* [tile][plane 3][W][64] */
+    const uint32_t *lane_mask;  /* [tile*64] bit rows at which a piece starts */
+    const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
+    const int *tile_row, *tile_out, *tile_nrows, *tile_amax;
+    const uint32_t *lmf, *lmr;  /* l-mer table entries (l-mer | weight << 24) per strand */
     const int64_t *lmoff;
-    const int *seg_seq, *seg_s0, *seg_slot, *tile_amax;
     const uint32_t *sb;
     int xw;
     const int *len;
     double c[GKM_MAXD1];
     GramOut out;
-    int cj, maxseg;
+    int cj;
 };
 
-constexpr int WD_LDS = 1024; /* >= max |n/2 - p| + 1 for n <= 2047 */
+constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| + 1 for n <= 2047 */
 
 typedef const uint32_t __attribute__((address_space(4))) * sgpr_words;
 
@@ -304,7 +313,7 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * Hit words are parked in a per-lane LDS queue and turned into weighted profile counts
  * in batches, so the hot loop has no data-dependent control flow besides the push.
  */
-template <int W, int L, int D, int VARIANT = 0>
+template <int W, int L, int D, bool PACKED, int VARIANT = 0>
 __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
@@ -320,10 +329,18 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
     __shared__ uint32_t s_list[2 * BS_SPAD];
     uint32_t *const s_h = s_list;              /* wave-wide list of hit words (+ trash slot) ...    */
     uint32_t *const s_meta = s_list + BS_SPAD; /* ... and their origin: w, delta, strand, row lane  */
-    __shared__ uint32_t rowbase[64];         /* l-mer table index of every lane's segment start   */
-    __shared__ uint32_t accl[(D + 1) * 64];  /* mismatch profile accumulators [m][lane]           */
-    constexpr int HALF = (W + 1) / 2;        /* the list is checked twice per shift               */
-    static_assert(BS_SBUF >= BS_TRIP + 64 * HALF, "hit list too small for W");
+    /* PACKED: lanes may hold several pieces (gkm_pack.h) and a tile up to MAX_ROWS rows.  When no
+     * lane of the call holds more than one piece (e.g. every fixed-length data set) the leaner
+     * variant runs: one (slot, base) pair per lane, at most 64 rows per tile, 3 KB less LDS
+     * (config 2: 113 ms against 120 ms with the general variant). */
+    constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
+    constexpr int NSLOT = PACKED ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
+    __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
+    __shared__ uint32_t lpiece[64 * NP * 2];     /* row slot, l-mer table base per piece       */
+    __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
+    constexpr int CHK = 5; /* the list is checked every CHK words (at most 64 * CHK new entries) */
+    static_assert(BS_SBUF >= BS_TRIP + 64 * CHK, "hit list too small");
+    static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
@@ -331,6 +348,16 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
     const int j0 = blockIdx.x * A.cj;
     const int j1 = min(j0 + A.cj, amax + 1);
     if (j0 >= j1) return;
+    const int nrows = A.tile_nrows[tile];
+    /* the row slots this lane finishes in the epilogue */
+    constexpr int NE = NSLOT / 64;
+    int my_row[NE], my_out[NE];
+#pragma unroll
+    for (int k = 0; k < NE; k++) {
+        const int rs = k * 64 + lane;
+        my_row[k] = rs < nrows ? A.tile_row[tile * gkmpack::MAX_ROWS + rs] : -1;
+        my_out[k] = rs < nrows ? A.tile_out[tile * gkmpack::MAX_ROWS + rs] : 0;
+    }
 
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
@@ -339,11 +366,10 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
         Alo[w] = A.rowplanes[(((size_t)tile * 3 + 1) * W + w) * 64 + lane];
         AV[w] = A.rowplanes[(((size_t)tile * 3 + 2) * W + w) * 64 + lane];
     }
-    const int myseq = A.seg_seq[tile * 64 + lane];
-    const int s0 = A.seg_s0[tile * 64 + lane];
-    const int slot = A.seg_slot[tile * 64 + lane];
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
-    rowbase[lane] = myseq >= 0 ? (uint32_t)(A.lmoff[myseq] + s0) : 0u;
+    if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
+#pragma unroll
+    for (int k = 0; k < NP * 2; k++) lpiece[lane * NP * 2 + k] = A.lane_piece[(size_t)(tile * 64 + lane) * NP * 2 + k];
     const uint32_t lane_tag = (uint32_t)lane << 18;
 
     for (int j = j0; j < j1; j++) {
@@ -353,18 +379,22 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
         const uint32_t *colf = A.lmf + A.lmoff[j], *colr = A.lmr + A.lmoff[j];
         auto col_lmer = [&](int strand, int q) { return strand ? colr[q] : colf[q]; };
 #pragma unroll
-        for (int k = 0; k <= D; k++) accl[k * 64 + lane] = 0u;
+        for (int m = 0; m <= D; m++)
+            for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
         int s_n = 0; /* words in the hit list (wave-uniform) */
 
-        /* one hit record -> accl[m][source lane] += wa * wb */
+        /* one hit record -> accl[m][row slot] += wa * wb.  The lane and bit row of the hit name the
+         * piece (gkm_pack.h), the piece names the row slot and where its l-mers sit in the table */
         auto resolve = [&](uint32_t rec) {
             if (VARIANT & 16) { atomicAdd(&accl[rec_lane(rec)], rec); return; } /* timing: no table reads */
             const int r = rec_lane(rec);
-            const uint32_t *rowf = A.lmf + rowbase[r];
-            auto row_lmer = [&](int i0) { return rowf[i0]; };
+            const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], rec_bit(rec)) : 0;
+            const uint32_t slot = lpiece[(r * NP + k) * 2];
+            const uint32_t base = lpiece[(r * NP + k) * 2 + 1]; /* lmoff[row] + p0 - b0*W (mod 2^32) */
+            auto row_lmer = [&](int i0) { return A.lmf[base + (uint32_t)i0]; };
             const HitValue hv = resolve_hit<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
                                                rcpT, nB, row_lmer, col_lmer);
-            atomicAdd(&accl[hv.m * 64 + r], hv.v); /* LDS atomic: ds_add_u32 */
+            if (hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
         /* Resolve the hit list in FULL trips of 2 x 64 words with every lane busy: each word gives
@@ -465,7 +495,7 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
                                 *(uint32_t *)((char *)s_h + at) = h;
                                 *(uint32_t *)((char *)s_meta + at) = vbase | (uint32_t)w;
                                 s_n += (int)__popcll(mask);
-                                if (w == HALF - 1 || w == W - 1) {
+                                if (w % CHK == CHK - 1 || w == W - 1) {
                                     if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
                                     else if (s_n >= BS_TRIP) trips(false);
                                 }
@@ -477,36 +507,21 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
         }
         trips(true);
 
-        uint32_t acc[D + 1];
+        /* epilogue: one lane per row slot of the tile */
 #pragma unroll
-        for (int k = 0; k <= D; k++) acc[k] = accl[k * 64 + lane];
-
-        /* a sequence longer than one segment occupies consecutive lanes: fold them */
-        if (A.maxseg > 1) {
-            uint32_t own[D + 1];
-#pragma unroll
-            for (int k = 0; k <= D; k++) own[k] = acc[k];
-            for (int s = 1; s < A.maxseg; s++) {
-                const int other = __shfl_down(myseq, s);
-                const bool same = (lane + s < 64) && (other == myseq) && (myseq >= 0);
-#pragma unroll
-                for (int k = 0; k <= D; k++) {
-                    const uint32_t t = __shfl_down(own[k], s);
-                    if (same) acc[k] += t;
-                }
-            }
-        }
-
-        if (myseq >= 0 && s0 == 0 && j <= myseq) {
+        for (int k = 0; k < NE; k++) {
+            const int rs = k * 64 + lane, row = my_row[k];
+            if (row < 0 || j > row) continue;
             /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
             double g = 0.0;
 #pragma unroll
-            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)acc[m];
-            const int64_t r = A.out.local_rows ? slot : myseq;
+            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)accl[m * NSLOT + rs];
+            const int64_t r = A.out.local_rows ? my_out[k] : row;
             A.out.G[r * A.out.ld + j] = g;
             if (A.out.P) {
 #pragma unroll
-                for (int m = 0; m <= D; m++) A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)acc[m];
+                for (int m = 0; m <= D; m++)
+                    A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)accl[m * NSLOT + rs];
             }
         }
     }
@@ -667,7 +682,7 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
 static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 {
     if (ctx->have_sb && ctx->sb_W == W) return 0;
-    const int xw = ((ctx->maxlen + W + BS_DU + 15) / 16) * 16;
+    const int xw = ((ctx->maxlen + W + 2 * BS_DU + 15) / 16) * 16;
     if (ctx->sb.ensure((size_t)ctx->n * 2 * 2 * (size_t)xw)) return 4;
     hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 2), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
                        W, ctx->L, xw, ctx->sb.p);
@@ -681,19 +696,18 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 /* ------------------------------------------------- host: launch dispatch */
 typedef void (*bs_kernel_t)(const BsArgs);
 
-template <int W>
+template <int W, bool PACKED>
 static bs_kernel_t pick_bitslice(int L, int d)
 {
 #define GKM_BS(LL, DD) \
-    if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD>;
+    if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
     if (L == 11 && d == 3) { /* timing experiments (tools/variants.sh); results are wrong for != 0 */
         const char *v = getenv("GKM_VARIANT");
         const int vi = v ? atoi(v) : 0;
-        if (vi == 1) return k_gram_bitslice<W, 11, 3, 1>;
-        if (vi == 2) return k_gram_bitslice<W, 11, 3, 2>;
-        if (vi == 4) return k_gram_bitslice<W, 11, 3, 4>;
-        if (vi == 16) return k_gram_bitslice<W, 11, 3, 16>;
-        if (vi == 32) return k_gram_bitslice<W, 11, 3, 32>;
+        if (vi == 1) return k_gram_bitslice<W, 11, 3, PACKED, 1>;
+        if (vi == 2) return k_gram_bitslice<W, 11, 3, PACKED, 2>;
+        if (vi == 16) return k_gram_bitslice<W, 11, 3, PACKED, 16>;
+        if (vi == 32) return k_gram_bitslice<W, 11, 3, PACKED, 32>;
     }
     GKM_BS(10, 3)
     GKM_BS(11, 3)
@@ -715,7 +729,6 @@ static bs_kernel_t pick_bitslice(int L, int d)
     return nullptr;
 }
 
-constexpr int BS_W = 10;
 
 extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
                                 int64_t ld, int32_t *P, int64_t ldp, void *stream_)
@@ -738,56 +751,65 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     GramOut out;
     out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows;
 
-    bs_kernel_t bs = nullptr;
-    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs = pick_bitslice<BS_W>(L, d);
-    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs)
+    /* W = 10 words per lane; W = 20 was measured too (config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms):
+     * the longer per-shift chain does not pay for the registers it costs */
+    bs_kernel_t bs10 = nullptr;
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = pick_bitslice<10, true>(L, d);
+    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs10)
         return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
 
-    if (bs) {
-        const int W = BS_W;
-        const int cap = gkmbs::segment_capacity(W, L);
+    if (bs10) {
+        /* pack the rows into lanes at bit-row granularity (gkm_pack.h) */
+        std::vector<int> nwin((size_t)nrows);
+        for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
+        const gkmpack::Packing pk = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L);
+        const int W = pk.W, ntiles = pk.ntiles;
+        /* no lane with a second piece -> the leaner kernel variant (also: at most 64 rows per tile) */
+        bool packed = getenv("GKM_FORCE_PACKED") != nullptr;
+        for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
+        const int NP = packed ? gkmpack::MAX_PIECES : 1;
+        bs_kernel_t bs = packed ? bs10 : pick_bitslice<10, false>(L, d);
         if (ensure_sb(ctx, W, stream) || ensure_lmers(ctx, stream)) return 4;
-        /* lay the rows out as tiles of 64 segments; all segments of one sequence share a tile */
-        std::vector<int> seg_seq, seg_s0, seg_slot, tile_amax;
-        int maxseg = 1;
-        for (int i = 0; i < nrows; i++) {
-            const int a = rows[i];
-            const int nwin = ctx->h_len[(size_t)a] - L + 1;
-            const int nseg = (nwin + cap - 1) / cap;
-            maxseg = std::max(maxseg, nseg);
-            const int used = (int)(seg_seq.size() % 64);
-            if (used + nseg > 64)
-                for (int k = used; k < 64; k++) { seg_seq.push_back(-1); seg_s0.push_back(0); seg_slot.push_back(0); }
-            for (int k = 0; k < nseg; k++) { seg_seq.push_back(a); seg_s0.push_back(k * cap); seg_slot.push_back(i); }
+        const size_t nl = (size_t)ntiles * 64;
+        std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
+        std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)NP * 2, 0u);
+        std::vector<int> fill(nl, 0);
+        for (const gkmpack::Piece &pc : pk.pieces) {
+            const int k = fill[(size_t)pc.lane]++;
+            int *dd = &desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
+            dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
+            lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
+            lane_piece[((size_t)pc.lane * NP + k) * 2] = (uint32_t)pc.slot;
+            lane_piece[((size_t)pc.lane * NP + k) * 2 + 1] =
+                (uint32_t)(ctx->h_lmoff[(size_t)pc.row] + pc.p0 - (int64_t)pc.b0 * W);
         }
-        while (seg_seq.size() % 64) { seg_seq.push_back(-1); seg_s0.push_back(0); seg_slot.push_back(0); }
-        const int ntiles = (int)(seg_seq.size() / 64);
-        tile_amax.assign((size_t)ntiles, -1);
-        for (size_t k = 0; k < seg_seq.size(); k++)
-            tile_amax[k / 64] = std::max(tile_amax[k / 64], seg_seq[k]);
-        if (ctx->seg_seq.ensure(seg_seq.size()) || ctx->seg_s0.ensure(seg_seq.size()) ||
-            ctx->seg_slot.ensure(seg_seq.size()) || ctx->tile_amax.ensure((size_t)ntiles) ||
-            ctx->rowplanes.ensure((size_t)ntiles * 3 * W * 64))
+        if (ctx->piece_desc.ensure(desc.size()) || ctx->lane_mask.ensure(nl) || ctx->lane_piece.ensure(lane_piece.size()) ||
+            ctx->tile_row.ensure(pk.tile_row.size()) || ctx->tile_out.ensure(pk.tile_out.size()) ||
+            ctx->tile_nrows.ensure((size_t)ntiles) || ctx->tile_amax.ensure((size_t)ntiles) ||
+            ctx->rowplanes.ensure(nl * 3 * W))
             return 4;
-        HIPCHK(hipMemcpyAsync(ctx->seg_seq.p, seg_seq.data(), seg_seq.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->seg_s0.p, seg_s0.data(), seg_s0.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->seg_slot.p, seg_slot.data(), seg_slot.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, tile_amax.data(), tile_amax.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->piece_desc.p, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->lane_mask.p, lane_mask.data(), nl * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->lane_piece.p, lane_piece.data(), lane_piece.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_row.p, pk.tile_row.data(), pk.tile_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_out.p, pk.tile_out.data(), pk.tile_out.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_nrows.p, pk.tile_nrows.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, pk.tile_amax.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
         /* the host vectors above are pageable: the copies have completed on return */
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, ctx->seg_seq.p, ctx->seg_s0.p, W, L, ctx->rowplanes.p);
+                           ctx->off.p, ctx->piece_desc.p, W, ctx->rowplanes.p);
         HIPCHK(hipGetLastError());
 
         BsArgs A;
-        A.rowplanes = ctx->rowplanes.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.lmoff = ctx->lmoff.p;
-        A.seg_seq = ctx->seg_seq.p; A.seg_s0 = ctx->seg_s0.p; A.seg_slot = ctx->seg_slot.p;
+        A.rowplanes = ctx->rowplanes.p; A.lane_mask = ctx->lane_mask.p; A.lane_piece = ctx->lane_piece.p;
+        A.tile_row = ctx->tile_row.p; A.tile_out = ctx->tile_out.p; A.tile_nrows = ctx->tile_nrows.p;
         A.tile_amax = ctx->tile_amax.p;
+        A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.lmoff = ctx->lmoff.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 4; /* small work items: better tail balance (sweep: 4 -> 192 ms, 16 -> 197, 64 -> 221) */
-        A.maxseg = maxseg;
         const char *e = getenv("GKM_CJ");
         if (e && atoi(e) > 0) A.cj = atoi(e);
         const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
@@ -795,7 +817,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         hipLaunchKernelGGL(bs, dim3(nchunks, (unsigned)ntiles), dim3(64), 0, stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, stream));
-        ctx->last_kernel = "k_gram_bitslice";
+        ctx->last_kernel = packed ? "k_gram_bitslice<packed>" : "k_gram_bitslice";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->rows.ensure((size_t)nrows)) return 4;

@@ -48,6 +48,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own HIP runtime: if this library (linked against /opt/rocm) were
+    # loaded first, torch would afterwards find "no HIP GPUs".  Import torch first when it exists
+    # so that one runtime serves both.  (The reference's own caller does not use torch at all.)
+    import importlib.util
+    if importlib.util.find_spec("torch") is not None:
+        import torch  # noqa: F401
     path = lib_path()
     if not os.path.exists(path):
         raise GkmError("%s is missing: build it with `make -C gkmqc_amd/csrc` "

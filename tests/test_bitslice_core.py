@@ -73,3 +73,36 @@ def test_lane_program_matches_oracle(libs, W, L, d):
         for t in (2, 4):
             assert (_oracle_profile(O, t, L, d, A, B) == _probe_profile(O, probe, W, t, L, d, A, B)).all(), \
                 (trial, t, la, lb)
+
+
+@pytest.mark.parametrize("W,L,d", [(10, 11, 3), (20, 11, 3), (10, 12, 4), (20, 12, 4), (20, 10, 3), (10, 6, 2), (20, 6, 2),
+                                   (5, 11, 3)])
+def test_packed_lanes_match_oracle(libs, W, L, d):
+    """Several row sequences packed into lanes at bit-row granularity (gkm_pack.h): packing
+    invariants (checked inside the probe) and per-row profiles against one column sequence."""
+    O, probe = libs
+    rng = np.random.default_rng(7 * W + 100 * L + d)
+    lens = list(rng.integers(L, 700, 60)) + [L, L + 1, 2047, 300, 300, 300, 320, 321, 150, 150, 150, 149, 640, 641]
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in lens]
+    seqs[5] = seqs[9].copy()
+    seqs[6][:] = 0                                    # poly-A row
+    codes = np.concatenate(seqs)
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    np.cumsum([len(s) for s in seqs], out=off[1:])
+    rows = np.arange(len(seqs), dtype=np.int32)
+    vp = ctypes.c_void_p
+    for t in (2, 4):
+        wd = _dist_table(O, t, 2047) if t == 4 else None
+        for col in (3, 6, 62, len(seqs) - 1):
+            P = np.zeros((len(seqs), d + 1), dtype=np.int32)
+            used = ctypes.c_int(0)
+            rc = probe.bsprobe_profile_packed(W, L, d, codes.ctypes.data_as(vp), off.ctypes.data_as(vp),
+                                              rows.ctypes.data_as(vp), len(rows), col,
+                                              wd.ctypes.data_as(vp) if wd is not None else None,
+                                              P.ctypes.data_as(vp), ctypes.byref(used))
+            assert rc == 0, "packing invariant %d violated" % rc
+            for i in (0, 5, 6, 9, 20, 41, 60, 61, 62, 63, 66, 67, 70, 73):
+                assert (P[i] == _oracle_profile(O, t, L, d, seqs[i], seqs[col])).all(), (t, col, i)
+    # the packing is dense: lanes used stay close to the information-theoretic minimum
+    need = sum(-(-len(s) // W) for s in seqs) / 32.0
+    assert used.value <= 1.25 * need + 2

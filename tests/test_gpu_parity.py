@@ -65,7 +65,7 @@ def test_quirks_bitslice_kernel(dev, quirk_seqs, idx):
         if "not instantiated" in str(e):
             pytest.skip("no bit-sliced instantiation for L=%d d=%d" % (c["L"], c["d"]))
         raise
-    assert res["kernel"] == "k_gram_bitslice"
+    assert res["kernel"].startswith("k_gram_bitslice")
     _check_against_case(res, c, len(seqs))
 
 
@@ -236,7 +236,7 @@ def test_every_bitslice_instantiation_against_the_general_kernel(dev, L, d):
     for t in (2, 4):
         a = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
         b = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_DIRECT)
-        assert a["kernel"] == "k_gram_bitslice" and b["kernel"] == "k_gram_direct"
+        assert a["kernel"].startswith("k_gram_bitslice") and b["kernel"] == "k_gram_direct"
         il = np.tril_indices(len(seqs))
         Pa, Pb = a["P"].cpu().numpy(), b["P"].cpu().numpy()
         assert (Pa[il] == Pb[il]).all()
@@ -245,3 +245,18 @@ def test_every_bitslice_instantiation_against_the_general_kernel(dev, L, d):
         want = _oracle_profiles(sub, t, L, k, d)
         is_ = np.tril_indices(len(sub))
         assert (Pa[:14, :14][is_] == want[is_]).all()
+
+
+def test_packed_variant_on_fixed_length_data(dev, monkeypatch):
+    """Fixed-length data normally takes the one-piece-per-lane variant; force the general
+    (several pieces per lane) variant on it as well."""
+    z = helpers.synthetic_expected()
+    seqs = helpers.synth_codes(192, 192, 300)
+    il = np.tril_indices(len(seqs))
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("GKM_FORCE_PACKED", "1")
+        res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        assert res["kernel"] == ("k_gram_bitslice<packed>" if forced else "k_gram_bitslice")
+        assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
+        assert helpers.max_rel_err(helpers.tril_pack(res["K"].cpu().numpy()), z["c2_cut192_K"]) < K_TOL
