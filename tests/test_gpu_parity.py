@@ -260,3 +260,37 @@ def test_packed_variant_on_fixed_length_data(dev, monkeypatch):
         assert res["kernel"] == ("k_gram_bitslice<packed>" if forced else "k_gram_bitslice")
         assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
         assert helpers.max_rel_err(helpers.tril_pack(res["K"].cpu().numpy()), z["c2_cut192_K"]) < K_TOL
+
+
+def test_tiny_and_degenerate_problems(dev, tmp_path):
+    """1 + 1 sequences, sequences of exactly L bases, many very short sequences (more rows than
+    a tile has row slots), through the boundary and through the device layer."""
+    rng = np.random.default_rng(3)
+
+    def fasta(path, seqs):
+        with open(path, "wb") as f:
+            for i, s in enumerate(seqs):
+                f.write(b">s%d\n" % i + bytes(b"ACGT"[c] for c in s) + b"\n")
+
+    # (a) the smallest legal problem through gkm_main_pywrapper
+    a, b = rng.integers(0, 4, 11).astype(np.uint8), rng.integers(0, 4, 40).astype(np.uint8)
+    pf, nf = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+    fasta(pf, [a])
+    fasta(nf, [b])
+    kmat = np.zeros((4, 4))
+    rows = (kmat.ctypes.data + np.arange(4) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.zeros(2, dtype=np.int32)
+    opt = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, pf.encode(), nf.encode(), 1, 0)
+    assert dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data) == 0
+    want = _oracle_profiles([a, b], 4, 11, 7, 3)
+    c = dev.mismatch_weights(4, 11, 7)[:4]
+    g = (want.astype(np.float64) * c).sum(axis=2)
+    assert tuple(sizes) == (1, 1) and kmat[0, 0] == 1.0 and kmat[1, 1] == 1.0 and kmat[0, 1] == 0.0
+    assert abs(kmat[1, 0] - g[1, 0] / np.sqrt(g[0, 0] * g[1, 1])) < 1e-15
+    # (b) 300 sequences of 11..40 bases: several rows per lane, more than 128 rows -> several tiles
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(11, 41, 300)]
+    want = _oracle_profiles(seqs, 2, 11, 7, 3)
+    il = np.tril_indices(len(seqs))
+    for kern in (dev.KERNEL_BITSLICE, dev.KERNEL_DIRECT):
+        res = dev.gram_matrix(seqs, 2, 11, 7, 3, want_profiles=True, kernel=kern)
+        assert (res["P"].cpu().numpy()[il] == want[il]).all(), res["kernel"]
