@@ -490,10 +490,11 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
                                 const unsigned long long mask = __ballot(h != 0u);
                                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                /* byte offsets so that the address is one v_lshl_add + one select */
-                                const uint32_t at = (h != 0u) ? (((uint32_t)rank << 2) + ((uint32_t)s_n << 2)) : (uint32_t)(BS_SBUF * 4);
-                                *(uint32_t *)((char *)s_h + at) = h;
-                                *(uint32_t *)((char *)s_meta + at) = vbase | (uint32_t)w;
+                                if (h != 0u) { /* EXEC-masked stores: no select, no trash slot needed */
+                                    const uint32_t at = ((uint32_t)rank << 2) + ((uint32_t)s_n << 2);
+                                    *(uint32_t *)((char *)s_h + at) = h;
+                                    *(uint32_t *)((char *)s_meta + at) = vbase | (uint32_t)w;
+                                }
                                 s_n += (int)__popcll(mask);
                                 if (w % CHK == CHK - 1 || w == W - 1) {
                                     if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
