@@ -137,7 +137,7 @@ struct gkmhip_ctx {
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch */
-    DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_amax;
+    DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_cbeg, tile_cend;
     DevBuf<uint32_t> rowplanes, lane_mask, lane_piece;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -185,7 +185,8 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
     ctx->rows.release(); ctx->piece_desc.release(); ctx->tile_row.release(); ctx->tile_out.release();
-    ctx->tile_nrows.release(); ctx->tile_amax.release(); ctx->rowplanes.release(); ctx->lane_mask.release();
+    ctx->tile_nrows.release(); ctx->tile_cbeg.release(); ctx->tile_cend.release(); ctx->rowplanes.release();
+    ctx->lane_mask.release();
     ctx->lane_piece.release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -256,18 +257,23 @@ __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64
 
 /* ------------------------------------------------------------ hot kernels */
 struct GramOut {
-    double *G;
+    double *G;      /* raw values G(a,j); may be NULL when only `diag` is wanted */
     int64_t ld;
     int32_t *P;
     int64_t ldp;
     int local_rows;
+    int write_all;  /* 0: only j <= a (lower triangle + diagonal); 1: every column visited */
+    double *diag;   /* if set: diag[a] = G(a,a) */
 };
+
+/* which columns a tile of rows visits */
+enum { COLS_TRIANGLE = 0, COLS_FULL = 1, COLS_DIAGONAL = 2 };
 
 struct BsArgs {
     const uint32_t *rowplanes;  /* [tile][plane 3][W][64] */
     const uint32_t *lane_mask;  /* [tile*64] bit rows at which a piece starts */
     const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
-    const int *tile_row, *tile_out, *tile_nrows, *tile_amax;
+    const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
     const uint32_t *lmf, *lmr;  /* l-mer table entries (l-mer | weight << 24) per strand */
     const int64_t *lmoff;
     const uint32_t *sb;
@@ -344,9 +350,8 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
 
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
-    const int amax = A.tile_amax[tile];
-    const int j0 = blockIdx.x * A.cj;
-    const int j1 = min(j0 + A.cj, amax + 1);
+    const int j0 = A.tile_cbeg[tile] + blockIdx.x * A.cj;
+    const int j1 = min(j0 + A.cj, A.tile_cend[tile]);
     if (j0 >= j1) return;
     const int nrows = A.tile_nrows[tile];
     /* the row slots this lane finishes in the epilogue */
@@ -512,13 +517,14 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
 #pragma unroll
         for (int k = 0; k < NE; k++) {
             const int rs = k * 64 + lane, row = my_row[k];
-            if (row < 0 || j > row) continue;
+            if (row < 0 || (j > row && !A.out.write_all)) continue;
             /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
             double g = 0.0;
 #pragma unroll
             for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)accl[m * NSLOT + rs];
             const int64_t r = A.out.local_rows ? my_out[k] : row;
-            A.out.G[r * A.out.ld + j] = g;
+            if (A.out.diag && j == row) A.out.diag[row] = g;
+            if (A.out.G) A.out.G[r * A.out.ld + j] = g;
             if (A.out.P) {
 #pragma unroll
                 for (int m = 0; m <= D; m++)
@@ -536,7 +542,7 @@ struct DirectArgs {
     const uint32_t *lmf, *lmr; /* l-mer | weight << 24 */
     double c[GKM_MAXD1];
     GramOut out;
-    int cj, L, d;
+    int cj, L, d, mode, n;
 };
 
 /*
@@ -552,9 +558,10 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
     const int tile = blockIdx.y;
     const int ridx = tile * 64 + lane;
     const int a = ridx < A.nrows ? A.rows[ridx] : -1;
-    const int amax = A.rows[min(tile * 64 + 63, A.nrows - 1)];
-    const int j0 = blockIdx.x * A.cj;
-    const int j1 = min(j0 + A.cj, amax + 1);
+    const int amin = A.rows[tile * 64], amax = A.rows[min(tile * 64 + 63, A.nrows - 1)];
+    const int cbeg = A.mode == COLS_DIAGONAL ? amin : 0, cend = A.mode == COLS_FULL ? A.n : amax + 1;
+    const int j0 = cbeg + blockIdx.x * A.cj;
+    const int j1 = min(j0 + A.cj, cend);
     if (j0 >= j1) return;
     const int d = A.d;
     const int na = a >= 0 ? A.len[a] - A.L + 1 : 0;
@@ -586,11 +593,12 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
                 }
             }
         }
-        if (a >= 0 && j <= a) {
+        if (a >= 0 && (j <= a || A.out.write_all)) {
             double g = 0.0;
             for (int m = 0; m <= d; m++) g += A.c[m] * (double)(int32_t)acc[m][lane];
             const int64_t r = A.out.local_rows ? ridx : a;
-            A.out.G[r * A.out.ld + j] = g;
+            if (A.out.diag && j == a) A.out.diag[a] = g;
+            if (A.out.G) A.out.G[r * A.out.ld + j] = g;
             if (A.out.P)
                 for (int m = 0; m <= d; m++) A.out.P[(r * A.out.ldp + j) * (d + 1) + m] = (int32_t)acc[m][lane];
         }
@@ -731,12 +739,13 @@ static bs_kernel_t pick_bitslice(int L, int d)
 }
 
 
-extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
-                                int64_t ld, int32_t *P, int64_t ldp, void *stream_)
+/* One launch of the Gram kernel for a set of rows.  mode says which columns every tile of rows
+ * visits: COLS_TRIANGLE j <= largest row of the tile (the path of gkm_main_pywrapper),
+ * COLS_FULL every sequence, COLS_DIAGONAL only the band of the tile's own rows (self norms). */
+static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, GramOut out, hipStream_t stream)
 {
-    if (!ctx || !rows || nrows <= 0 || !G) return set_err_msg("gkmhip_gram_rows: bad arguments", 2);
-    if (ctx->n <= 0) return set_err_msg("gkmhip_gram_rows: no sequences uploaded", 2);
-    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx || !rows || nrows <= 0) return set_err_msg("gram: bad arguments", 2);
+    if (ctx->n <= 0) return set_err_msg("gram: no sequences uploaded", 2);
     HIPCHK(hipSetDevice(ctx->device));
     const int L = ctx->L, d = ctx->d, n = ctx->n;
     double comparisons = 0;
@@ -744,13 +753,9 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         if (rows[i] < 0 || rows[i] >= n || (i > 0 && rows[i] <= rows[i - 1]))
             return set_err_msg("rows must be strictly ascending sequence indices", 2);
         const double na = (double)(ctx->h_len[(size_t)rows[i]] - L + 1);
-        comparisons += 2.0 * na * ctx->h_cum_n[(size_t)rows[i] + 1];
+        comparisons += 2.0 * na * (mode == COLS_FULL ? ctx->h_cum_n[(size_t)n] : mode == COLS_DIAGONAL ? na : ctx->h_cum_n[(size_t)rows[i] + 1]);
     }
-    if (ld <= rows[nrows - 1]) return set_err_msg("leading dimension too small", 2);
-    const int amax_all = rows[nrows - 1];
-
-    GramOut out;
-    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows;
+    out.write_all = mode == COLS_FULL ? 1 : 0;
 
     /* W = 10 words per lane; W = 20 was measured too (config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms):
      * the longer per-shift chain does not pay for the registers it costs */
@@ -786,7 +791,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         }
         if (ctx->piece_desc.ensure(desc.size()) || ctx->lane_mask.ensure(nl) || ctx->lane_piece.ensure(lane_piece.size()) ||
             ctx->tile_row.ensure(pk.tile_row.size()) || ctx->tile_out.ensure(pk.tile_out.size()) ||
-            ctx->tile_nrows.ensure((size_t)ntiles) || ctx->tile_amax.ensure((size_t)ntiles) ||
+            ctx->tile_nrows.ensure((size_t)ntiles) || ctx->tile_cbeg.ensure((size_t)ntiles) || ctx->tile_cend.ensure((size_t)ntiles) ||
             ctx->rowplanes.ensure(nl * 3 * W))
             return 4;
         HIPCHK(hipMemcpyAsync(ctx->piece_desc.p, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice, stream));
@@ -795,7 +800,17 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         HIPCHK(hipMemcpyAsync(ctx->tile_row.p, pk.tile_row.data(), pk.tile_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->tile_out.p, pk.tile_out.data(), pk.tile_out.size() * sizeof(int), hipMemcpyHostToDevice, stream));
         HIPCHK(hipMemcpyAsync(ctx->tile_nrows.p, pk.tile_nrows.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_amax.p, pk.tile_amax.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
+        int span = 0;
+        for (int t = 0; t < ntiles; t++) {
+            int amin = n;
+            for (int rs = 0; rs < pk.tile_nrows[(size_t)t]; rs++) amin = std::min(amin, pk.tile_row[(size_t)t * gkmpack::MAX_ROWS + rs]);
+            cbeg[(size_t)t] = mode == COLS_DIAGONAL ? amin : 0;
+            cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
+            span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
+        }
+        HIPCHK(hipMemcpyAsync(ctx->tile_cbeg.p, cbeg.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->tile_cend.p, cend.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
         /* the host vectors above are pageable: the copies have completed on return */
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
                            ctx->off.p, ctx->piece_desc.p, W, ctx->rowplanes.p);
@@ -804,7 +819,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         BsArgs A;
         A.rowplanes = ctx->rowplanes.p; A.lane_mask = ctx->lane_mask.p; A.lane_piece = ctx->lane_piece.p;
         A.tile_row = ctx->tile_row.p; A.tile_out = ctx->tile_out.p; A.tile_nrows = ctx->tile_nrows.p;
-        A.tile_amax = ctx->tile_amax.p;
+        A.tile_cbeg = ctx->tile_cbeg.p; A.tile_cend = ctx->tile_cend.p;
         A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.lmoff = ctx->lmoff.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
@@ -813,7 +828,7 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         A.cj = 4; /* small work items: better tail balance (sweep: 4 -> 192 ms, 16 -> 197, 64 -> 221) */
         const char *e = getenv("GKM_CJ");
         if (e && atoi(e) > 0) A.cj = atoi(e);
-        const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
+        const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
         HIPCHK(hipEventRecord(ctx->ev0, stream));
         hipLaunchKernelGGL(bs, dim3(nchunks, (unsigned)ntiles), dim3(64), 0, stream, A);
         HIPCHK(hipGetLastError());
@@ -828,9 +843,14 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
         A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
-        A.cj = 16; A.L = L; A.d = d;
+        A.cj = 16; A.L = L; A.d = d; A.mode = mode; A.n = n;
         const unsigned ntiles = (unsigned)((nrows + 63) / 64);
-        const unsigned nchunks = (unsigned)((amax_all + 1 + A.cj - 1) / A.cj);
+        int span = 0; /* widest column range of any 64-row tile */
+        for (unsigned t = 0; t < ntiles; t++) {
+            const int amin = rows[t * 64], amax = rows[std::min<int>((int)t * 64 + 63, nrows - 1)];
+            span = std::max(span, mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1);
+        }
+        const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
         HIPCHK(hipEventRecord(ctx->ev0, stream));
         hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
         HIPCHK(hipGetLastError());
@@ -839,6 +859,77 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     }
     ctx->ev_valid = true;
     ctx->last_comparisons = comparisons;
+    return 0;
+}
+
+extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                int64_t ld, int32_t *P, int64_t ldp, void *stream_)
+{
+    if (!G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows: bad arguments", 2);
+    if (ld <= rows[nrows - 1]) return set_err_msg("leading dimension too small", 2);
+    GramOut out;
+    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows; out.write_all = 0; out.diag = nullptr;
+    return gram_launch(ctx, rows, nrows, COLS_TRIANGLE, out, (hipStream_t)stream_);
+}
+
+extern "C" int gkmhip_gram_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                     int64_t ld, void *stream_)
+{
+    if (!ctx || !G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows_full: bad arguments", 2);
+    if (ld < ctx->n) return set_err_msg("leading dimension too small", 2);
+    GramOut out;
+    out.G = G; out.ld = ld; out.P = nullptr; out.ldp = 0; out.local_rows = local_rows; out.write_all = 1; out.diag = nullptr;
+    return gram_launch(ctx, rows, nrows, COLS_FULL, out, (hipStream_t)stream_);
+}
+
+__global__ void k_sqrt_inplace(double *__restrict__ v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = sqrt(v[i]); /* libgkm.c:753-758 */
+}
+
+extern "C" int gkmhip_self_norms(gkmhip_ctx *ctx, double *sqnorm, void *stream_)
+{
+    if (!ctx || !sqnorm || ctx->n <= 0) return set_err_msg("gkmhip_self_norms: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<int> all((size_t)ctx->n);
+    for (int i = 0; i < ctx->n; i++) all[(size_t)i] = i;
+    GramOut out;
+    out.G = nullptr; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 0; out.write_all = 0; out.diag = sqnorm;
+    const int rc = gram_launch(ctx, all.data(), ctx->n, COLS_DIAGONAL, out, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sqrt_inplace, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, stream, sqnorm, ctx->n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* K(rows[i], j) = G / (sq[rows[i]] * sq[j]) for every column j of a block of full rows */
+__global__ void k_normalize_full(double *__restrict__ G, int64_t ld, const int *__restrict__ rows, int local_rows, int n,
+                                 const double *__restrict__ sq, int rbf, double gamma)
+{
+    const int a = rows[blockIdx.y];
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double *cell = G + (int64_t)(local_rows ? (int)blockIdx.y : a) * ld + j;
+    double v = 1.0;
+    if (j != a) {
+        v = *cell / (sq[a] * sq[j]);
+        if (rbf) v = exp(gamma * (v - 1));
+    }
+    *cell = v;
+}
+
+extern "C" int gkmhip_normalize_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                          int64_t ld, const double *sqnorm, void *stream_)
+{
+    if (!ctx || !rows || nrows <= 0 || !G || !sqnorm) return set_err_msg("gkmhip_normalize_rows_full: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    if (ctx->rows.ensure((size_t)nrows)) return 4;
+    HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_normalize_full, dim3((unsigned)((ctx->n + 255) / 256), (unsigned)nrows), dim3(256), 0, stream, G, ld,
+                       ctx->rows.p, local_rows, ctx->n, sqnorm, ctx->rbf, ctx->gamma);
+    HIPCHK(hipGetLastError());
     return 0;
 }
 

@@ -95,6 +95,12 @@ def load():
     L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, i32, vp)
     L.gkmhip_gram_rows.restype = i32
     L.gkmhip_gram_rows.argtypes = (vp, vp, i32, i32, vp, i64, vp, i64, vp)
+    L.gkmhip_gram_rows_full.restype = i32
+    L.gkmhip_gram_rows_full.argtypes = (vp, vp, i32, i32, vp, i64, vp)
+    L.gkmhip_self_norms.restype = i32
+    L.gkmhip_self_norms.argtypes = (vp, vp, vp)
+    L.gkmhip_normalize_rows_full.restype = i32
+    L.gkmhip_normalize_rows_full.argtypes = (vp, vp, i32, i32, vp, i64, vp, vp)
     L.gkmhip_normalize.restype = i32
     L.gkmhip_normalize.argtypes = (vp, vp, i64, vp, i32, vp)
     L.gkmhip_malloc.restype = vp
@@ -237,6 +243,19 @@ class GramContext:
         self._chk(self.lib.gkmhip_gram_rows(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr, ld,
                                             P_ptr, ldp, stream), "gkmhip_gram_rows")
 
+    def gram_rows_full(self, rows, G_ptr, ld, local_rows=True, stream=0):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self._chk(self.lib.gkmhip_gram_rows_full(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr, ld,
+                                                 stream), "gkmhip_gram_rows_full")
+
+    def self_norms(self, sq_ptr, stream=0):
+        self._chk(self.lib.gkmhip_self_norms(self.handle, sq_ptr, stream), "gkmhip_self_norms")
+
+    def normalize_rows_full(self, rows, G_ptr, ld, sq_ptr, local_rows=True, stream=0):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        self._chk(self.lib.gkmhip_normalize_rows_full(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr,
+                                                      ld, sq_ptr, stream), "gkmhip_normalize_rows_full")
+
     def normalize(self, G_ptr, ld, sq_ptr=None, symmetric=False, stream=0):
         self._chk(self.lib.gkmhip_normalize(self.handle, G_ptr, ld, sq_ptr, int(symmetric), stream),
                   "gkmhip_normalize")
@@ -249,6 +268,30 @@ class GramContext:
 
     def last_kernel_name(self):
         return self.lib.gkmhip_last_kernel_name(self.handle).decode()
+
+
+def cross_kernel(seqs, rows, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, kernel=KERNEL_AUTO):
+    """K(rows[i], j) for every sequence j (prediction-style rectangular kernel): torch fp64
+    [len(rows), n] with 1.0 where j == rows[i], plus the self norms."""
+    import torch
+    ctx = GramContext(kernel_type, L, k, d, M, H, gamma, device)
+    try:
+        ctx.set_kernel(kernel)
+        dev = torch.device("cuda", device)
+        with torch.cuda.device(dev):
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx.set_sequences(seqs, stream)
+            n = len(seqs)
+            rows = np.ascontiguousarray(sorted(rows), dtype=np.int32)
+            G = torch.zeros((len(rows), n), dtype=torch.float64, device=dev)
+            sq = torch.zeros(n, dtype=torch.float64, device=dev)
+            ctx.self_norms(sq.data_ptr(), stream)
+            ctx.gram_rows_full(rows, G.data_ptr(), n, True, stream)
+            ctx.normalize_rows_full(rows, G.data_ptr(), n, sq.data_ptr(), True, stream)
+            torch.cuda.synchronize(dev)
+            return dict(K=G, sqnorm=sq, rows=rows, kernel=ctx.last_kernel_name())
+    finally:
+        ctx.close()
 
 
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,

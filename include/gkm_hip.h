@@ -68,6 +68,22 @@ int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int
 int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
                      int64_t ld, int32_t *P, int64_t ldp, void *stream);
 
+/* Rectangular variant for prediction-style use (the batch-vs-support-vector call of the
+ * reference, gkmkernel_kernelfunc_batch, src/libgkm.c:1115-1153): raw G(rows[i], j) for EVERY
+ * uploaded sequence j (not only j <= a).  G needs ld >= n. */
+int gkmhip_gram_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G, int64_t ld,
+                          void *stream);
+
+/* sqnorm[i] = sqrt(G(i,i)) for all uploaded sequences (device array of n doubles), computed
+ * from the diagonal band only (~1 % of the work of the whole matrix).  Replaces
+ * gkmkernel_kernelfunc_sqnorm_single, src/libgkm.c:723-759. */
+int gkmhip_self_norms(gkmhip_ctx *ctx, double *sqnorm, void *stream);
+
+/* K(rows[i], j) = G / (sqnorm[rows[i]] sqnorm[j]) (+ RBF), 1.0 where j == rows[i], for rows written by
+ * gkmhip_gram_rows_full with the same rows / local_rows. */
+int gkmhip_normalize_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G, int64_t ld,
+                               const double *sqnorm, void *stream);
+
 /* In place on a device matrix holding raw values for ALL n rows (lower triangle +
  * diagonal): K(a,j) = G(a,j) / (sqrt(G(a,a)) sqrt(G(j,j))), optional RBF, K(a,a)=1.
  * If sqnorm != NULL (device, n doubles) it receives sqrt(G(a,a)).

@@ -294,3 +294,21 @@ def test_tiny_and_degenerate_problems(dev, tmp_path):
     for kern in (dev.KERNEL_BITSLICE, dev.KERNEL_DIRECT):
         res = dev.gram_matrix(seqs, 2, 11, 7, 3, want_profiles=True, kernel=kern)
         assert (res["P"].cpu().numpy()[il] == want[il]).all(), res["kernel"]
+
+
+@pytest.mark.parametrize("kernel", ["bitslice", "direct"])
+def test_rectangular_kernel_and_self_norms(dev, kernel):
+    """gkmhip_gram_rows_full / gkmhip_self_norms / gkmhip_normalize_rows_full: K(a, j) for every j
+    equals the symmetric completion of the triangular matrix (the profile is symmetric,
+    SURVEY.md App. A.3), self norms from the diagonal band equal those of the full run."""
+    seqs = helpers.synth_codes(60, 70, 300, (120, 650))
+    kern = dev.KERNEL_BITSLICE if kernel == "bitslice" else dev.KERNEL_DIRECT
+    full = dev.gram_matrix(seqs, 4, 11, 7, 3, kernel=kern)
+    K = full["K"].cpu().numpy()
+    Ksym = np.tril(K) + np.tril(K, -1).T
+    rows = [0, 3, 4, 59, 60, 61, 100, 129]
+    rect = dev.cross_kernel(seqs, rows, 4, 11, 7, 3, kernel=kern)
+    assert (rect["sqnorm"].cpu().numpy() == full["sqnorm"].cpu().numpy()).all()
+    got = rect["K"].cpu().numpy()
+    for i, a in enumerate(rect["rows"]):
+        assert (got[i] == Ksym[a]).all(), a
