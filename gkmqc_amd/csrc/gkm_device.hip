@@ -66,35 +66,39 @@ extern "C" int gkmhip_device_count(void)
 /* Pinned staging for device-to-host copies, kept for the life of the process: the pipeline
  * calls the boundary once per peak subset (20x per run, bin/gkmqc.py:341-343) and pinning
  * 2 x 64 MB costs ~30 ms per call otherwise.  gkmhip_release_host_cache() frees it. */
+constexpr int STAGE_SLOTS = 16; /* one pair of buffers per concurrently copying device thread */
 static std::mutex g_stage_mutex;
-static double *g_stage[2] = {nullptr, nullptr};
-static size_t g_stage_bytes = 0;
+static double *g_stage[STAGE_SLOTS][2];
+static size_t g_stage_bytes[STAGE_SLOTS];
 
-static int acquire_staging(size_t want, double **out)
+static int acquire_staging(size_t want, double **out, int slot)
 {
+    if (slot < 0 || slot >= STAGE_SLOTS) return set_err_msg("too many device threads", 2);
     std::lock_guard<std::mutex> lock(g_stage_mutex);
-    if (g_stage_bytes < want) {
+    if (g_stage_bytes[slot] < want) {
         for (int i = 0; i < 2; i++) {
-            if (g_stage[i]) (void)hipHostFree(g_stage[i]);
-            g_stage[i] = nullptr;
+            if (g_stage[slot][i]) (void)hipHostFree(g_stage[slot][i]);
+            g_stage[slot][i] = nullptr;
         }
-        g_stage_bytes = 0;
-        for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&g_stage[i], want, hipHostMallocDefault));
-        g_stage_bytes = want;
+        g_stage_bytes[slot] = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&g_stage[slot][i], want, hipHostMallocPortable));
+        g_stage_bytes[slot] = want;
     }
-    out[0] = g_stage[0];
-    out[1] = g_stage[1];
+    out[0] = g_stage[slot][0];
+    out[1] = g_stage[slot][1];
     return 0;
 }
 
 extern "C" void gkmhip_release_host_cache(void)
 {
     std::lock_guard<std::mutex> lock(g_stage_mutex);
-    for (int i = 0; i < 2; i++) {
-        if (g_stage[i]) (void)hipHostFree(g_stage[i]);
-        g_stage[i] = nullptr;
+    for (int s = 0; s < STAGE_SLOTS; s++) {
+        for (int i = 0; i < 2; i++) {
+            if (g_stage[s][i]) (void)hipHostFree(g_stage[s][i]);
+            g_stage[s][i] = nullptr;
+        }
+        g_stage_bytes[s] = 0;
     }
-    g_stage_bytes = 0;
 }
 
 /* ----------------------------------------------------------------- context */
@@ -936,10 +940,12 @@ extern "C" int gkmhip_normalize_rows_full(gkmhip_ctx *ctx, const int *rows, int 
 /* rows r0..r1-1 of a matrix whose rows < r1 hold raw values: needs sqrt(G(j,j)) for j < r1 only,
  * so row blocks can be normalised (and shipped) in ascending order while later ones compute */
 static int normalize_rows(gkmhip_ctx *ctx, double *G, int64_t ld, int r0, int r1, double *sq, int symmetric,
-                          hipStream_t stream)
+                          hipStream_t stream, bool have_norms = false)
 {
-    hipLaunchKernelGGL(k_sqnorm, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, stream, G, ld, r0, r1, sq);
-    HIPCHK(hipGetLastError());
+    if (!have_norms) { /* take the norms of these rows from their own diagonal */
+        hipLaunchKernelGGL(k_sqnorm, dim3((unsigned)((r1 - r0 + 255) / 256)), dim3(256), 0, stream, G, ld, r0, r1, sq);
+        HIPCHK(hipGetLastError());
+    }
     hipLaunchKernelGGL(k_normalize, dim3((unsigned)((r1 + 255) / 256), (unsigned)(r1 - r0)), dim3(256), 0, stream, G,
                        ld, r0, sq, ctx->rbf, ctx->gamma, symmetric);
     HIPCHK(hipGetLastError());
@@ -962,31 +968,39 @@ extern "C" int gkmhip_normalize(gkmhip_ctx *ctx, double *G, int64_t ld, double *
 
 /* Whole matrix into caller-owned host rows (rows[a][0..a]) as a pipeline over row blocks of
  * about equal work: block k+1 is computed while block k travels device -> pinned staging ->
- * the caller's (pageable) rows.  G is device scratch of n x ld doubles. */
-extern "C" int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads)
+ * the caller's (pageable) rows.  G is device scratch of n x ld doubles.
+ * part / nparts: this context handles every nparts-th block (several GPUs driven by one host
+ * process, one context and thread each, all writing disjoint rows of the same host matrix);
+ * with nparts > 1 the self norms come from a diagonal-band pass first, so that no device needs
+ * another device's rows. */
+static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads, int part,
+                                  int nparts)
 {
-    if (!ctx || !G || !rows || ctx->n <= 0 || ld < ctx->n) return set_err_msg("gkmhip_gram_to_host_rows: bad arguments", 2);
+    if (!ctx || !G || !rows || ctx->n <= 0 || ld < ctx->n || nparts < 1 || part < 0 || part >= nparts)
+        return set_err_msg("gkmhip_gram_to_host_rows: bad arguments", 2);
     HIPCHK(hipSetDevice(ctx->device));
     const int n = ctx->n;
     const size_t want = (size_t)64 << 20;
     double *stage[2];
-    if (acquire_staging(want, stage)) return 4;
+    if (acquire_staging(want, stage, part)) return 4;
     if (ctx->sq.ensure((size_t)n)) return 4;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
 
-    /* blocks: at most 1/12 of the triangle's area each, and a staging rectangle that fits */
+    /* blocks: at most 1/12 (1/(4 nparts)) of the triangle's area each, and a staging rectangle that fits */
     struct Blk { int r0, r1; };
     std::vector<Blk> blocks;
-    const double area_cap = (double)n * n / 24.0;
+    const double area_cap = (double)n * n / (2.0 * std::max(12, 4 * nparts));
+    int index = 0;
     for (int r0 = 0; r0 < n;) {
         int r1 = r0 + 1;
         while (r1 < n && (size_t)(r1 + 1) * (size_t)(r1 + 1 - r0) * 8 <= want &&
                ((double)(r1 + 1) * (r1 + 1) - (double)r0 * r0) / 2.0 <= area_cap)
             r1++;
-        blocks.push_back({r0, r1});
+        if (index++ % nparts == part) blocks.push_back({r0, r1});
         r0 = r1;
     }
+    if (blocks.empty()) return 0;
     const size_t B = blocks.size();
     const bool trace = getenv("GKM_TRACE") != nullptr;
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -998,11 +1012,12 @@ extern "C" int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, 
     std::vector<hipEvent_t> done(B, nullptr);
     int rc = 0;
     std::vector<int> idx;
+    if (nparts > 1) rc = gkmhip_self_norms(ctx, ctx->sq.p, sc);
     for (size_t b = 0; b < B && !rc; b++) { /* enqueue all the compute up front */
         idx.resize((size_t)(blocks[b].r1 - blocks[b].r0));
         for (size_t i = 0; i < idx.size(); i++) idx[i] = blocks[b].r0 + (int)i;
         rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sc);
-        if (!rc) rc = normalize_rows(ctx, G, ld, blocks[b].r0, blocks[b].r1, ctx->sq.p, 0, sc);
+        if (!rc) rc = normalize_rows(ctx, G, ld, blocks[b].r0, blocks[b].r1, ctx->sq.p, 0, sc, nparts > 1);
         if (!rc && hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) rc = 4;
         if (!rc && hipEventRecord(done[b], sc) != hipSuccess) rc = 4;
     }
@@ -1052,6 +1067,17 @@ extern "C" int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, 
     return 0;
 }
 
+extern "C" int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads)
+{
+    return gram_part_to_host_rows(ctx, G, ld, rows, nthreads, 0, 1);
+}
+
+extern "C" int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads,
+                                             int part, int nparts)
+{
+    return gram_part_to_host_rows(ctx, G, ld, rows, nthreads, part, nparts);
+}
+
 /* ------------------------------------------------------- memory helpers */
 extern "C" void *gkmhip_malloc(int device, size_t bytes)
 {
@@ -1088,7 +1114,7 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
     HIPCHK(hipSetDevice(ctx->device));
     const size_t want = (size_t)64 << 20;
     double *stage[2];
-    if (acquire_staging(want, stage)) return 4;
+    if (acquire_staging(want, stage, 0)) return 4;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
     hipStream_t s;

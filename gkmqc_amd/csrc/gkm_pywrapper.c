@@ -7,6 +7,7 @@
  * rows are computed on the GPU.  There is NO CPU compute path: without a usable HIP
  * device the call logs an ERROR and returns non-zero.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -14,6 +15,41 @@
 
 #include "../../include/gkm_hip.h"
 #include "gkm_host.h"
+
+#define GKM_MAX_DEVICES 16
+
+/* one GPU's share when the boundary call spreads the matrix over several devices */
+typedef struct {
+    int device, part, nparts, L, d;
+    const double *c;
+    int rbf;
+    double gamma;
+    int n;
+    const uint8_t *codes;
+    const int64_t *offsets;
+    const uint8_t *wd;
+    int wd_len;
+    double **kmat;
+    int nthreads;
+    int rc;
+    char err[256];
+} device_job;
+
+static void *device_worker(void *arg)
+{
+    device_job *j = (device_job *)arg;
+    gkmhip_ctx *ctx = gkmhip_create(j->device, j->L, j->d, j->c, j->rbf, j->gamma);
+    double *dG = NULL;
+    j->rc = 1;
+    if (ctx && !gkmhip_set_sequences(ctx, j->n, j->codes, j->offsets, j->wd, j->wd_len, NULL) &&
+        (dG = (double *)gkmhip_malloc(j->device, (size_t)j->n * (size_t)j->n * sizeof(double))) != NULL &&
+        !gkmhip_gram_part_to_host_rows(ctx, dG, j->n, j->kmat, j->nthreads, j->part, j->nparts))
+        j->rc = 0;
+    if (j->rc) snprintf(j->err, sizeof j->err, "%s", gkmhip_last_error());
+    if (dG) gkmhip_free(dG);
+    if (ctx) gkmhip_destroy(ctx);
+    return NULL;
+}
 
 static double now_ms(void)
 {
@@ -118,31 +154,79 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     }
     const double t_parsed = now_ms();
 
-    int device = 0;
-    const char *env = getenv("GKM_DEVICE");
-    if (env) device = atoi(env);
-    ctx = gkmhip_create(device, L, d, c, rbf, opts->gamma);
-    const double t_created = now_ms();
-    if (!ctx) {
-        gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
-        goto done;
+    /* devices: GKM_DEVICES = "all", a count ("4") or a list ("0,2,3"); GKM_DEVICE = one ordinal.
+     * Several GPUs: one context + host thread per device, each filling disjoint row blocks of the
+     * caller's matrix (no collective needed: the result goes to host memory anyway). */
+    int devs[GKM_MAX_DEVICES], ndev = 0;
+    {
+        const char *list = getenv("GKM_DEVICES");
+        const char *one = getenv("GKM_DEVICE");
+        const int avail = gkmhip_device_count();
+        if (list && *list) {
+            if (!strcmp(list, "all")) {
+                for (int i = 0; i < avail && ndev < GKM_MAX_DEVICES; i++) devs[ndev++] = i;
+            } else if (strchr(list, ',')) {
+                for (const char *q = list; *q && ndev < GKM_MAX_DEVICES;) {
+                    devs[ndev++] = atoi(q);
+                    q = strchr(q, ',');
+                    if (!q) break;
+                    q++;
+                }
+            } else {
+                for (int i = 0; i < atoi(list) && ndev < GKM_MAX_DEVICES; i++) devs[ndev++] = i;
+            }
+        }
+        if (ndev == 0) devs[ndev++] = one ? atoi(one) : 0;
     }
-    if (gkmhip_set_sequences(ctx, n, gkm_problem_all_codes(prob), gkm_problem_offsets(prob), wd, wd_len, NULL)) {
-        gkm_log(GKM_LOG_ERROR, "device upload failed: %s", gkmhip_last_error());
-        goto done;
-    }
-    const double t_uploaded = now_ms();
-    dG = (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
-    const double t_alloc = now_ms();
-    if (!dG) {
-        gkm_log(GKM_LOG_ERROR, "device allocation of the %d x %d matrix failed: %s", n, n, gkmhip_last_error());
-        goto done;
-    }
-    /* rows a: K(a, 0..a-1) and the unit diagonal -- exactly the cells the reference writes;
-     * computed, normalised and shipped block by block (compute overlaps the PCIe transfer) */
-    if (gkmhip_gram_to_host_rows(ctx, dG, n, kmat, opts->nthreads > 0 ? opts->nthreads : 1)) {
-        gkm_log(GKM_LOG_ERROR, "gram kernel failed: %s", gkmhip_last_error());
-        goto done;
+    double t_created = t_parsed, t_uploaded = t_parsed, t_alloc = t_parsed;
+    if (ndev == 1) {
+        const int device = devs[0];
+        ctx = gkmhip_create(device, L, d, c, rbf, opts->gamma);
+        t_created = now_ms();
+        if (!ctx) {
+            gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
+            goto done;
+        }
+        if (gkmhip_set_sequences(ctx, n, gkm_problem_all_codes(prob), gkm_problem_offsets(prob), wd, wd_len, NULL)) {
+            gkm_log(GKM_LOG_ERROR, "device upload failed: %s", gkmhip_last_error());
+            goto done;
+        }
+        t_uploaded = now_ms();
+        dG = (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
+        t_alloc = now_ms();
+        if (!dG) {
+            gkm_log(GKM_LOG_ERROR, "device allocation of the %d x %d matrix failed: %s", n, n, gkmhip_last_error());
+            goto done;
+        }
+        /* rows a: K(a, 0..a-1) and the unit diagonal -- exactly the cells the reference writes;
+         * computed, normalised and shipped block by block (compute overlaps the PCIe transfer) */
+        if (gkmhip_gram_to_host_rows(ctx, dG, n, kmat, opts->nthreads > 0 ? opts->nthreads : 1)) {
+            gkm_log(GKM_LOG_ERROR, "gram kernel failed: %s", gkmhip_last_error());
+            goto done;
+        }
+    } else {
+        device_job jobs[GKM_MAX_DEVICES];
+        pthread_t th[GKM_MAX_DEVICES];
+        int started[GKM_MAX_DEVICES];
+        for (int i = 0; i < ndev; i++) {
+            device_job j = {devs[i], i, ndev, L, d, c, rbf, opts->gamma, n, gkm_problem_all_codes(prob),
+                            gkm_problem_offsets(prob), wd, wd_len, kmat, opts->nthreads > 0 ? opts->nthreads : 1, 0, {0}};
+            jobs[i] = j;
+            started[i] = (i > 0 && pthread_create(&th[i], NULL, device_worker, &jobs[i]) == 0);
+        }
+        device_worker(&jobs[0]);
+        for (int i = 1; i < ndev; i++) {
+            if (started[i]) pthread_join(th[i], NULL);
+            else device_worker(&jobs[i]); /* could not start a thread: do that share here */
+        }
+        int failed = 0;
+        for (int i = 0; i < ndev; i++)
+            if (jobs[i].rc) {
+                gkm_log(GKM_LOG_ERROR, "HIP device %d: %s", jobs[i].device, jobs[i].err);
+                failed = 1;
+            }
+        if (failed) goto done;
+        gkm_log(GKM_LOG_DEBUG, "row blocks computed on %d devices", ndev);
     }
     const double t_kernel = now_ms();
     kmat_size[0] = n_pos;
@@ -150,7 +234,7 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     rc = 0;
     gkm_log(GKM_LOG_DEBUG, "timing: read+tables %.1f ms, context %.1f ms, upload %.1f ms, device malloc %.1f ms, "
             "gram + copy-out pipeline %.1f ms (kernel %s)", t_parsed - t_start, t_created - t_parsed,
-            t_uploaded - t_created, t_alloc - t_uploaded, t_kernel - t_alloc, gkmhip_last_kernel_name(ctx));
+            t_uploaded - t_created, t_alloc - t_uploaded, t_kernel - t_alloc, ctx ? gkmhip_last_kernel_name(ctx) : "multi");
 
 done:;
     const double t_done = now_ms();

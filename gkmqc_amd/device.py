@@ -117,6 +117,9 @@ def load():
     L.gkmhip_copy_lower_to_rows.argtypes = (vp, vp, i64, i32, vp, i32)
     L.gkmhip_gram_to_host_rows.restype = i32
     L.gkmhip_gram_to_host_rows.argtypes = (vp, vp, i64, vp, i32)
+    L.gkmhip_gram_part_to_host_rows.restype = i32
+    L.gkmhip_gram_part_to_host_rows.argtypes = (vp, vp, i64, vp, i32, i32, i32)
+    L.gkmhip_release_host_cache.restype = None
     L.gkmhip_last_kernel_ms.restype = dbl
     L.gkmhip_last_kernel_ms.argtypes = (vp,)
     L.gkmhip_last_comparisons.restype = dbl

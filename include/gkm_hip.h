@@ -109,6 +109,13 @@ int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64_t ld, int 
  * G: device scratch of n x ld doubles.  This is what gkm_main_pywrapper uses. */
 int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads);
 
+/* The same for one of `nparts` contexts (one per GPU, one host thread each) filling disjoint row
+ * blocks of ONE host matrix: context `part` takes every nparts-th block; self norms come from a
+ * diagonal-band pass, so no device needs another device's rows and no collective is involved.
+ * This is how gkm_main_pywrapper uses several GPUs of a node (GKM_DEVICES). */
+int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads, int part,
+                                  int nparts);
+
 /* The pinned staging buffers of the copy-out calls (2 x 64 MB) are kept for the life of the
  * process; this releases them (optional). */
 void gkmhip_release_host_cache(void);

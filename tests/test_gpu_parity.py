@@ -312,3 +312,31 @@ def test_rectangular_kernel_and_self_norms(dev, kernel):
     got = rect["K"].cpu().numpy()
     for i, a in enumerate(rect["rows"]):
         assert (got[i] == Ksym[a]).all(), a
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+def test_boundary_over_several_device_contexts(dev, monkeypatch, devices):
+    """GKM_DEVICES: the boundary call spreads row blocks over one context + host thread per listed
+    device (the same GPU listed several times on a one-GPU box): identical matrix."""
+    z = helpers.synthetic_expected()
+    import tempfile
+    from gkmqc_amd import synth
+    tmp = tempfile.mkdtemp()
+    pf, nf = os.path.join(tmp, "p.fa"), os.path.join(tmp, "n.fa")
+    synth.write_problem(pf, nf, 192, 192, 300)
+    n = 384
+
+    def call():
+        kmat = np.zeros((n, n))
+        rows = (kmat.ctypes.data + np.arange(n) * kmat.strides[0]).astype(np.uintp)
+        sizes = np.zeros(2, dtype=np.int32)
+        opt = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, pf.encode(), nf.encode(), 2, 0)
+        assert dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data) == 0
+        return kmat
+
+    one = call()
+    monkeypatch.setenv("GKM_DEVICES", devices)
+    many = call()
+    assert (one == many).all()
+    assert (np.triu(many, 1) == 0).all() and (np.diag(many) == 1.0).all()
+    assert helpers.max_rel_err(helpers.tril_pack(many), z["c2_cut192_K"]) < K_TOL
