@@ -472,6 +472,8 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
             const sb_ptr sbh = (sb_ptr)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
             const sb_ptr sbl = sbh + A.xw;
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
+                /* (copying the words to VGPRs once instead of using them as SGPR operands was measured
+                 * slower: 119-129 ms against 111.6 ms on config 2) */
                 /* the strand's window-validity plane (third SB plane) is not streamed: wrapped
                  * windows are rejected when a hit is resolved (gkm_bitslice.h window_hits) */
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
