@@ -1,0 +1,446 @@
+/*
+ * gkm_svm.hip -- C-SVC on a precomputed kernel resident in HBM (include/gkm_svm.h, SURVEY.md
+ * §8(f4)).  One workgroup per problem (cross-validation fold); all folds of a CV run
+ * concurrently on different CUs.  The iteration is LIBSVM's SMO with second-order working-set
+ * selection and no shrinking (Fan, Chen, Lin 2005), restated so that every floating-point
+ * operation and every tie break matches the sequential solver: same alpha, same rho.
+ *
+ * Per iteration (l = training samples, each thread owns up to R of them, strided):
+ *   A  i = argmax over I_up of -y G          (ties: the LARGER index, LIBSVM scans with >=)
+ *   B  gather Q_i = (float)(y_i y_k K_ik), j = argmin over I_low of -(grad_diff^2)/quad (ties: larger
+ *      index, LIBSVM scans with <=), Gmax2; stop when Gmax + Gmax2 < eps
+ *   C  thread 0 updates alpha_i, alpha_j with LIBSVM's clipping
+ *   D  gather Q_j, G_k += Q_ik dalpha_i + Q_jk dalpha_j
+ * The kernel matrix is only read (two row gathers per iteration, served by L2).
+ */
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "../../include/gkm_svm.h"
+
+static thread_local std::string g_svm_err;
+extern "C" const char *gkmsvm_last_error(void) { return g_svm_err.c_str(); }
+static int svm_fail(const char *what, hipError_t e)
+{
+    g_svm_err = std::string(what) + ": " + hipGetErrorString(e);
+    return 100 + (int)e;
+}
+#define SVMCHK(expr)                                   \
+    do {                                               \
+        hipError_t e_ = (expr);                        \
+        if (e_ != hipSuccess) return svm_fail(#expr, e_); \
+    } while (0)
+
+constexpr int SVM_MAX_R = 16;      /* samples per thread */
+constexpr int SVM_MAX_THREADS = 1024;
+constexpr int SVM_MAX_L = SVM_MAX_THREADS * SVM_MAX_R;
+constexpr double SVM_TAU = 1e-12;
+
+struct SvmProb {
+    const int *idx;
+    int l, n0;
+    double *alpha, *grad, *rho;
+    int *iters;
+};
+
+/* A candidate of the working-set selection together with everything the other threads need to
+ * know about it, so that one LDS record per wave (and one barrier) publishes the winner. */
+struct Cand {
+    double v;      /* selection value */
+    double alpha, G, qd, q; /* of sample k: dual variable, gradient, K_kk, Q_ik (second index only) */
+    int k;         /* position in the problem (-1: none) */
+    int g;         /* row/column of K */
+};
+
+/* LIBSVM scans t = 0..l-1 and replaces the incumbent on `>=` (first index) or `<=` (second
+ * index): among equal values the LARGER index wins. */
+template <bool MINIMISE>
+__device__ __forceinline__ bool better(double v, int k, double bv, int bk)
+{
+    if (k < 0) return false;
+    if (bk < 0) return true;
+    return MINIMISE ? (v < bv || (v == bv && k > bk)) : (v > bv || (v == bv && k > bk));
+}
+
+template <bool MINIMISE>
+__device__ __forceinline__ void wave_select(double &v, int &k)
+{
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        const double ov = __shfl_xor(v, s);
+        const int ok = __shfl_xor(k, s);
+        if (better<MINIMISE>(ov, ok, v, k)) { v = ov; k = ok; }
+    }
+}
+
+__global__ void k_diag(const double *__restrict__ K, int64_t ld, int n, double *__restrict__ diag)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) diag[i] = K[(int64_t)i * ld + i];
+}
+
+/*
+ * One workgroup of T threads per problem.  Thread t owns samples t, t+T, ...: their alpha, G,
+ * matrix index and diagonal live in registers for the whole solve.  Two barriers per iteration:
+ * after each of the two selections the winning lane of every wave publishes its candidate with
+ * its payload in LDS, every thread then picks the block winner from the T/64 records and does
+ * the (scalar) two-variable update redundantly, so no third exchange is needed.
+ */
+template <int T, int SVM_R>
+__global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t ld, const double *__restrict__ diag,
+                                           const SvmProb *probs, double C, double eps, int max_iter)
+{
+    constexpr int NW = T / 64;
+    __shared__ Cand candA[NW], candB[NW];
+    __shared__ double g2s[NW];
+    __shared__ double chunk[T];
+    const SvmProb p = probs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = p.l, n0 = p.n0;
+
+    int gidx[SVM_R];
+    double qd[SVM_R], al[SVM_R], G[SVM_R];
+#pragma unroll
+    for (int r = 0; r < SVM_R; r++) {
+        const int k = tid + r * T;
+        gidx[r] = k < l ? p.idx[k] : 0;
+        qd[r] = k < l ? diag[gidx[r]] : 0.0;
+        al[r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1 */
+        G[r] = -1.0;
+    }
+
+    int iter = 0;
+    for (;; iter++) {
+        if (iter >= max_iter) { iter = -iter; break; }
+        /* ---- first index: argmax over I_up of -y G ---- */
+        double bv = -INFINITY;
+        int bk = -1;
+#pragma unroll
+        for (int r = 0; r < SVM_R; r++) {
+            const int k = tid + r * T;
+            if (k >= l) continue;
+            if (k < n0) { /* y = +1 */
+                if (al[r] < C && better<false>(-G[r], k, bv, bk)) { bv = -G[r]; bk = k; }
+            } else {
+                if (al[r] > 0.0 && better<false>(G[r], k, bv, bk)) { bv = G[r]; bk = k; }
+            }
+        }
+        wave_select<false>(bv, bk);
+        if (bk < 0) {
+            if (lane == 0) candA[wave].k = -1;
+        } else if ((bk & 63) == lane) { /* k = tid + r T, T a multiple of 64: the owner is lane k % 64 */
+            const int rr = (bk - tid) / T;
+#pragma unroll
+            for (int r = 0; r < SVM_R; r++)
+                if (r == rr) candA[wave] = {bv, al[r], G[r], qd[r], 0.0, bk, gidx[r]};
+        }
+        __syncthreads();
+        Cand ci = candA[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            const Cand o = candA[w];
+            if (better<false>(o.v, o.k, ci.v, ci.k)) ci = o;
+        }
+        const int i = ci.k;
+        if (i < 0) break;
+        const double Gmax = ci.v;
+        const double yi = i < n0 ? 1.0 : -1.0;
+        const double *Ki = K + (int64_t)ci.g * ld;
+        const double QDi = ci.qd;
+
+        /* ---- second index: argmin over I_low of -(grad_diff^2)/quad, and Gmax2 ---- */
+        float qik[SVM_R]; /* Q_ik is a float in LIBSVM (Qfloat): half the registers */
+        double kik[SVM_R];
+        double mv = INFINITY, g2max = -INFINITY;
+        int mk = -1;
+#pragma unroll
+        for (int r = 0; r < SVM_R; r++) kik[r] = tid + r * T < l ? Ki[gidx[r]] : 0.0;
+#pragma unroll
+        for (int r = 0; r < SVM_R; r++) {
+            const int k = tid + r * T;
+            if (k >= l) continue;
+            const double yk = k < n0 ? 1.0 : -1.0;
+            qik[r] = (float)(yi * yk * kik[r]);
+            const double q = (double)qik[r];
+            double grad_diff, quad;
+            if (k < n0) {
+                if (!(al[r] > 0.0)) continue; /* is_lower_bound */
+                grad_diff = Gmax + G[r];
+                g2max = fmax(g2max, G[r]);
+                quad = QDi + qd[r] - 2.0 * yi * q;
+            } else {
+                if (!(al[r] < C)) continue; /* is_upper_bound */
+                grad_diff = Gmax - G[r];
+                g2max = fmax(g2max, -G[r]);
+                quad = QDi + qd[r] + 2.0 * yi * q;
+            }
+            if (grad_diff > 0.0) {
+                const double od = quad > 0.0 ? -(grad_diff * grad_diff) / quad : -(grad_diff * grad_diff) / SVM_TAU;
+                if (better<true>(od, k, mv, mk)) { mv = od; mk = k; }
+            }
+        }
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) g2max = fmax(g2max, __shfl_xor(g2max, s));
+        wave_select<true>(mv, mk);
+        if (lane == 0) g2s[wave] = g2max;
+        if (mk < 0) {
+            if (lane == 0) candB[wave].k = -1;
+        } else if ((mk & 63) == lane) {
+            const int rr = (mk - tid) / T;
+#pragma unroll
+            for (int r = 0; r < SVM_R; r++)
+                if (r == rr) candB[wave] = {mv, al[r], G[r], qd[r], (double)qik[r], mk, gidx[r]};
+        }
+        __syncthreads();
+        Cand cj = candB[0];
+        double Gmax2 = g2s[0];
+#pragma unroll
+        for (int w = 1; w < NW; w++) {
+            const Cand o = candB[w];
+            if (better<true>(o.v, o.k, cj.v, cj.k)) cj = o;
+            Gmax2 = fmax(Gmax2, g2s[w]);
+        }
+        const int j = cj.k;
+        if (Gmax + Gmax2 < eps || j < 0) break;
+
+        /* ---- the two-variable sub-problem, LIBSVM's clipping order (every thread, same result) ---- */
+        const double yj = j < n0 ? 1.0 : -1.0;
+        const double Qij = cj.q, QDj = cj.qd;
+        double ai = ci.alpha, aj = cj.alpha;
+        const double old_i = ai, old_j = aj;
+        if (yi != yj) {
+            double quad = QDi + QDj + 2 * Qij;
+            if (quad <= 0) quad = SVM_TAU;
+            const double delta = (-ci.G - cj.G) / quad;
+            const double diff = ai - aj;
+            ai += delta;
+            aj += delta;
+            if (diff > 0) {
+                if (aj < 0) { aj = 0; ai = diff; }
+            } else {
+                if (ai < 0) { ai = 0; aj = -diff; }
+            }
+            if (diff > 0) { /* C_i - C_j = 0 */
+                if (ai > C) { ai = C; aj = C - diff; }
+            } else {
+                if (aj > C) { aj = C; ai = C + diff; }
+            }
+        } else {
+            double quad = QDi + QDj - 2 * Qij;
+            if (quad <= 0) quad = SVM_TAU;
+            const double delta = (ci.G - cj.G) / quad;
+            const double sum = ai + aj;
+            ai -= delta;
+            aj += delta;
+            if (sum > C) {
+                if (ai > C) { ai = C; aj = sum - C; }
+            } else {
+                if (aj < 0) { aj = 0; ai = sum; }
+            }
+            if (sum > C) {
+                if (aj > C) { aj = C; ai = sum - C; }
+            } else {
+                if (ai < 0) { ai = 0; aj = sum; }
+            }
+        }
+        const double dai = ai - old_i, daj = aj - old_j;
+
+        /* ---- gradient; the owners store the new alpha ---- */
+        const double *Kj = K + (int64_t)cj.g * ld;
+        double kj[SVM_R];
+#pragma unroll
+        for (int r = 0; r < SVM_R; r++) kj[r] = tid + r * T < l ? Kj[gidx[r]] : 0.0;
+#pragma unroll
+        for (int r = 0; r < SVM_R; r++) {
+            const int k = tid + r * T;
+            if (k >= l) continue;
+            const double yk = k < n0 ? 1.0 : -1.0;
+            const double qjk = (double)(float)(yj * yk * kj[r]);
+            G[r] += (double)qik[r] * dai + qjk * daj;
+            if (k == i) al[r] = ai;
+            if (k == j) al[r] = aj;
+        }
+    }
+
+#pragma unroll
+    for (int r = 0; r < SVM_R; r++) {
+        const int k = tid + r * T;
+        if (k < l) { p.alpha[k] = al[r]; p.grad[k] = G[r]; }
+    }
+
+    /* rho (LIBSVM calculate_rho).  The mean over the free vectors is summed in index order by one
+     * thread (bit-identical to the sequential solver); the values pass through LDS T at a time. */
+    int nr_free = 0;
+    double ub = INFINITY, lb = -INFINITY, sum_free = 0;
+#pragma unroll
+    for (int r = 0; r < SVM_R; r++) {
+        if (r * T >= l) break;
+        const int k = tid + r * T;
+        const double y = k < n0 ? 1.0 : -1.0;
+        double yG = y * G[r];
+        bool is_free = false;
+        if (k < l) {
+            if (al[r] >= C) {
+                if (y < 0) ub = fmin(ub, yG); else lb = fmax(lb, yG);
+            } else if (al[r] <= 0) {
+                if (y > 0) ub = fmin(ub, yG); else lb = fmax(lb, yG);
+            } else {
+                is_free = true;
+            }
+        }
+        __syncthreads();
+        chunk[tid] = is_free ? yG : NAN; /* NaN marks "not free" (a gradient is never NaN here) */
+        __syncthreads();
+        if (tid == 0) {
+            const int m = l - r * T < T ? l - r * T : T;
+            for (int t = 0; t < m; t++) {
+                const double x = chunk[t];
+                if (x == x) { ++nr_free; sum_free += x; }
+            }
+        }
+    }
+    /* ub / lb: plain min / max, any order */
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) {
+        ub = fmin(ub, __shfl_xor(ub, s));
+        lb = fmax(lb, __shfl_xor(lb, s));
+    }
+    __syncthreads();
+    if (lane == 0) { chunk[wave] = ub; chunk[NW + wave] = lb; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 0; w < NW; w++) { ub = fmin(ub, chunk[w]); lb = fmax(lb, chunk[NW + w]); }
+        *p.rho = nr_free > 0 ? sum_free / nr_free : (ub + lb) / 2;
+        *p.iters = iter;
+    }
+}
+
+struct DecProb {
+    const int *idx;
+    int l, n0;
+    const double *alpha, *rho;
+    const int *test;
+    int ntest;
+    double *dec;
+};
+
+/* one thread per test sample; the sum runs over the training samples in LIBSVM's order.  K is
+ * bit-symmetric (include/gkm_svm.h), so K(test_t, train_k) is read as K[train_k][test_t]: the
+ * threads of a wave then read neighbouring addresses of one matrix row. */
+__global__ void k_decision(const double *__restrict__ K, int64_t ld, const DecProb *probs)
+{
+    const DecProb p = probs[blockIdx.y];
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= p.ntest) return;
+    const int col = p.test[t];
+    double sum = 0;
+    for (int k = 0; k < p.l; k++) {
+        const double a = p.alpha[k]; /* wave-uniform */
+        if (a > 0) sum += (k < p.n0 ? a : -a) * K[(int64_t)p.idx[k] * ld + col];
+    }
+    p.dec[t] = sum - *p.rho;
+}
+
+extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob, const int *idx,
+                                  const int64_t *off, const int *n0, double C, double eps, double *alpha, double *grad,
+                                  double *rho, int *iters, void *stream_)
+{
+    if (!K || n <= 0 || ld < n || nprob <= 0 || !idx || !off || !n0 || !alpha || !grad || !rho || !iters) {
+        g_svm_err = "gkmsvm_train_batch: bad arguments";
+        return 2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    SVMCHK(hipSetDevice(device));
+    std::vector<SvmProb> h((size_t)nprob);
+    int64_t maxl = 0;
+    for (int p = 0; p < nprob; p++) {
+        const int64_t l = off[p + 1] - off[p];
+        if (l > maxl) maxl = l;
+        if (l <= 0 || l > (int64_t)SVM_MAX_L || n0[p] < 0 || n0[p] > l) {
+            g_svm_err = "gkmsvm_train_batch: a problem has no samples or more than 16384";
+            return 3;
+        }
+        h[(size_t)p] = {idx + off[p], (int)l, n0[p], alpha + off[p], grad + off[p], rho + p, iters + p};
+    }
+    SvmProb *dprobs = nullptr;
+    SVMCHK(hipMalloc((void **)&dprobs, sizeof(SvmProb) * (size_t)nprob));
+    SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(SvmProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
+    SVMCHK(hipStreamSynchronize(stream)); /* h is a host temporary */
+    double *diag = nullptr;
+    SVMCHK(hipMalloc((void **)&diag, sizeof(double) * (size_t)n));
+    hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
+    /* fewest threads and registers that hold the largest problem: narrower reductions, fewer waves
+     * per barrier, no spills (GKM_SVM_SHAPE=<threads>x<samples per thread> overrides, for timing) */
+    const int max_iter = 10000000;
+    int T = 0, R = 0;
+    const char *force = getenv("GKM_SVM_SHAPE");
+    if (force) sscanf(force, "%dx%d", &T, &R);
+    if (!force || (int64_t)T * R < maxl) {
+        if (maxl <= 256 * 4) { T = 256; R = 4; }
+        else if (maxl <= 512 * 4) { T = 512; R = 4; }
+        else if (maxl <= 512 * 8) { T = 512; R = 8; }
+        else if (maxl <= 1024 * 8) { T = 1024; R = 8; }
+        else { T = 1024; R = 16; }
+    }
+#define SMO_LAUNCH(TT, RR)                                                                                          \
+    if (T == TT && R == RR)                                                                                         \
+        hipLaunchKernelGGL((k_smo<TT, RR>), dim3((unsigned)nprob), dim3(TT), 0, stream, K, ld, diag, dprobs, C, eps, \
+                           max_iter);                                                                               \
+    else
+    SMO_LAUNCH(256, 4)
+    SMO_LAUNCH(512, 4)
+    SMO_LAUNCH(256, 8)
+    SMO_LAUNCH(512, 8)
+    SMO_LAUNCH(1024, 4)
+    SMO_LAUNCH(1024, 8)
+    SMO_LAUNCH(512, 16)
+    SMO_LAUNCH(1024, 16)
+    {
+        g_svm_err = "GKM_SVM_SHAPE: unsupported shape";
+        (void)hipFree(diag);
+        (void)hipFree(dprobs);
+        return 4;
+    }
+#undef SMO_LAUNCH
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(diag);
+    (void)hipFree(dprobs);
+    if (e != hipSuccess) return svm_fail("k_smo", e);
+    return 0;
+}
+
+extern "C" int gkmsvm_decision_batch(int device, const double *K, int64_t ld, int nprob, const int *idx,
+                                     const int64_t *off, const int *n0, const double *alpha, const double *rho,
+                                     const int *test_idx, const int64_t *test_off, double *dec, void *stream_)
+{
+    if (!K || nprob <= 0 || !idx || !off || !n0 || !alpha || !rho || !test_idx || !test_off || !dec) {
+        g_svm_err = "gkmsvm_decision_batch: bad arguments";
+        return 2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    SVMCHK(hipSetDevice(device));
+    std::vector<DecProb> h((size_t)nprob);
+    int maxtest = 0;
+    for (int p = 0; p < nprob; p++) {
+        const int nt = (int)(test_off[p + 1] - test_off[p]);
+        h[(size_t)p] = {idx + off[p], (int)(off[p + 1] - off[p]), n0[p], alpha + off[p], rho + p,
+                        test_idx + test_off[p], nt, dec + test_off[p]};
+        if (nt > maxtest) maxtest = nt;
+    }
+    if (maxtest == 0) return 0;
+    DecProb *dprobs = nullptr;
+    SVMCHK(hipMalloc((void **)&dprobs, sizeof(DecProb) * (size_t)nprob));
+    SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(DecProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(k_decision, dim3((unsigned)((maxtest + 127) / 128), (unsigned)nprob), dim3(128), 0, stream, K, ld,
+                       dprobs);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    (void)hipFree(dprobs);
+    if (e != hipSuccess) return svm_fail("k_decision", e);
+    return 0;
+}

@@ -17,6 +17,9 @@ Differences (all above the C ABI, none changes a number):
     SURVEY.md App. B #11).
 `computeGkmKernel(..., backend="boundary")` instead drives `gkm_main_pywrapper` exactly like the
 reference does (row pointers into a zeroed matrix) -- useful to validate a drop-in install.
+`computeGkmKernel(..., resident=True)` leaves the symmetrised matrix in HBM (torch CUDA tensor);
+`crossValidate` then runs every fold on the GPU (gkmqc_amd/svmcv.py) with
+results bit-identical to scikit-learn's solver.  `--svm-solver sklearn` keeps the reference's.
 """
 import argparse
 import ctypes
@@ -32,7 +35,7 @@ from . import device
 _KMAT = None  # shared with forked CV workers, like the reference's module global
 
 
-def computeGkmKernel(args_gkm, backend="device", gpu=0):
+def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False):
     """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity]."""
     kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, nproc, verbosity = args_gkm
     if backend == "boundary":
@@ -58,6 +61,8 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0):
     res = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=gpu)
     K = res["K"]                               # lower triangle + unit diagonal, zeros above
     K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97
+    if resident:
+        return K, n_pos, len(seqs) - n_pos
     return K.cpu().numpy(), n_pos, len(seqs) - n_pos
 
 
@@ -79,6 +84,9 @@ def _svm_fold(job):
 
 def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs):
     """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p]."""
+    if not isinstance(_kmat, np.ndarray):      # torch CUDA tensor: the matrix stays in HBM
+        from . import svmcv
+        return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs)
     from sklearn.model_selection import StratifiedKFold
     global _KMAT
     ncv, repeats, fast_estimation, random_seeds, p = args_svm[4:9]
@@ -110,7 +118,7 @@ def init(pos_fa, neg_fa, args):
     args_gkm = [args.kernel_type, args.full_word_length, args.non_gap_length, args.max_num_gaps, args.init_decay,
                 args.half_life_decay, args.rbf_gamma, pos_fa, neg_fa, args.n_processes, args.verbosity]
     logging.info("%s: building up kernel matrix", pos_fa)
-    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm)
+    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm, resident=getattr(args, "svm_solver", "gpu") == "gpu")
     args_svm = [args.regularization, args.precision, args.shrinking, args.cache_size, args.ncv, args.repeats,
                 args.fast_estimation, args.random_seeds, args.n_processes]
     logging.info("%s: svm training", pos_fa)
@@ -147,6 +155,8 @@ def build_parser():
     v.add_argument("-c", "--cache-size", type=int, default=512, help="cache memory size in MB (default: 512)")
     v.add_argument("-x", "--ncv", type=int, default=5, help="x-fold cross validation (default: 5)")
     v.add_argument("-r", "--repeats", type=int, default=1, help="repeats of CV training (default: 1)")
+    v.add_argument("--svm-solver", choices=("gpu", "sklearn"), default="gpu",
+                   help="gpu: all folds on the GPU-resident matrix (default); sklearn: the reference's solver")
     v.add_argument("-f", "--fast-estimation", type=int, default=0, help="not supported (dead code in the reference)")
     return parser
 

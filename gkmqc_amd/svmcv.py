@@ -1,0 +1,155 @@
+"""Cross-validation of a C-SVC on a gkm kernel matrix that stays in HBM -- SURVEY.md §8(f4).
+
+The reference trains `sklearn.svm.SVC(kernel="precomputed")` once per fold on host copies of the
+matrix (`scripts/gkmsvm.py:104-125`, fancy-indexed sub-matrices, one process per fold).  Here the
+matrix never leaves the GPU: every fold of every repeat is one workgroup of `k_smo`
+(gkmqc_amd/csrc/gkm_svm.hip, include/gkm_svm.h) reading the resident matrix through index lists,
+and the decision values come from `k_decision`.  Only the index lists go up and the per-fold
+decision values (a few thousand doubles) come back; fold generation (StratifiedKFold) and the AUC
+stay scikit-learn's so that the folds and the metric are the reference's own.
+
+Parity (tests/test_svm_gpu.py): dual coefficients, intercept and decision values bit-identical to
+scikit-learn's LIBSVM on the same matrix, hence identical AUC.
+"""
+import ctypes
+import logging
+
+import numpy as np
+
+from . import device
+
+
+class SvmError(RuntimeError):
+    pass
+
+
+def _lib():
+    L = device.load()
+    if not hasattr(L, "_svm_bound"):
+        vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
+        L.gkmsvm_train_batch.restype = i32
+        L.gkmsvm_train_batch.argtypes = (i32, vp, i64, i32, i32, vp, vp, vp, dbl, dbl, vp, vp, vp, vp, vp)
+        L.gkmsvm_decision_batch.restype = i32
+        L.gkmsvm_decision_batch.argtypes = (i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
+        L.gkmsvm_last_error.restype = ctypes.c_char_p
+        L._svm_bound = True
+    return L
+
+
+def libsvm_order(train, y):
+    """Training indices in LIBSVM's internal order (sklearn's svm_group_classes: classes sorted by
+    label, the samples of a class in their original order) and the size of class 0."""
+    train = np.asarray(train)
+    lab = np.asarray(y)[train]
+    classes = np.unique(lab)
+    if len(classes) != 2:
+        raise SvmError("a fold needs samples of exactly two classes")
+    first = train[lab == classes[0]]
+    second = train[lab == classes[1]]
+    return np.concatenate((first, second)).astype(np.int32), int(len(first))
+
+
+class FoldSolutions:
+    """Result of `train_folds`: per-fold alpha (LIBSVM order), rho, iteration count."""
+
+    def __init__(self, idx, n0, alpha, grad, rho, iters):
+        self.idx, self.n0, self.alpha, self.grad, self.rho, self.iters = idx, n0, alpha, grad, rho, iters
+
+    def dual_coef(self, f):
+        """sklearn's `dual_coef_[0]` and `support_` of fold f (positions in the fold's `train`)."""
+        a = self.alpha[f]
+        ysign = np.where(np.arange(len(a)) < self.n0[f], 1.0, -1.0)
+        sv = np.nonzero(a > 0)[0]
+        return -(a[sv] * ysign[sv]), self.idx[f][sv]
+
+
+def train_folds(K, trains, y, C=1.0, tol=1e-3):
+    """Solve one C-SVC per entry of `trains` (index arrays into the symmetric torch CUDA fp64
+    matrix K) concurrently.  Returns (FoldSolutions, device handles for `decision_values`)."""
+    import torch
+    if not (K.is_cuda and K.dtype == torch.float64 and K.dim() == 2 and K.shape[0] == K.shape[1]
+            and K.stride(1) == 1):
+        raise SvmError("K must be a square fp64 CUDA tensor with unit column stride")
+    L = _lib()
+    dev = K.device
+    orders = [libsvm_order(t, y) for t in trains]
+    idx = [o[0] for o in orders]
+    n0 = np.array([o[1] for o in orders], dtype=np.int32)
+    off = np.zeros(len(idx) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(i) for i in idx])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        d_idx = torch.from_numpy(np.concatenate(idx)).to(dev)
+        d_alpha = torch.empty(int(off[-1]), dtype=torch.float64, device=dev)
+        d_grad = torch.empty_like(d_alpha)
+        d_rho = torch.empty(len(idx), dtype=torch.float64, device=dev)
+        d_it = torch.empty(len(idx), dtype=torch.int32, device=dev)
+        rc = L.gkmsvm_train_batch(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx), d_idx.data_ptr(),
+                                  off.ctypes.data, n0.ctypes.data, float(C), float(tol), d_alpha.data_ptr(),
+                                  d_grad.data_ptr(), d_rho.data_ptr(), d_it.data_ptr(), stream)
+        if rc:
+            raise SvmError("gkmsvm_train_batch: %s" % L.gkmsvm_last_error().decode())
+        alpha = d_alpha.cpu().numpy()
+        grad = d_grad.cpu().numpy()
+        rho = d_rho.cpu().numpy()
+        iters = d_it.cpu().numpy()
+    if (iters < 0).any():
+        logging.warning("SMO hit the iteration cap in %d fold(s)", int((iters < 0).sum()))
+    sol = FoldSolutions(idx, n0, [alpha[off[f]:off[f + 1]] for f in range(len(idx))],
+                        [grad[off[f]:off[f + 1]] for f in range(len(idx))], rho, iters)
+    return sol, dict(idx=d_idx, off=off, n0=n0, alpha=d_alpha, rho=d_rho)
+
+
+def decision_values(K, handles, tests):
+    """scikit-learn's `decision_function` of every fold on its test samples (list of arrays)."""
+    import torch
+    L = _lib()
+    dev = K.device
+    toff = np.zeros(len(tests) + 1, dtype=np.int64)
+    toff[1:] = np.cumsum([len(t) for t in tests])
+    with torch.cuda.device(dev):
+        stream = torch.cuda.current_stream().cuda_stream
+        d_test = torch.from_numpy(np.concatenate(tests).astype(np.int32)).to(dev)
+        d_dec = torch.empty(int(toff[-1]), dtype=torch.float64, device=dev)
+        rc = L.gkmsvm_decision_batch(dev.index or 0, K.data_ptr(), K.stride(0), len(tests), handles["idx"].data_ptr(),
+                                     handles["off"].ctypes.data, handles["n0"].ctypes.data,
+                                     handles["alpha"].data_ptr(), handles["rho"].data_ptr(), d_test.data_ptr(),
+                                     toff.ctypes.data, d_dec.data_ptr(), stream)
+        if rc:
+            raise SvmError("gkmsvm_decision_batch: %s" % L.gkmsvm_last_error().decode())
+        dec = d_dec.cpu().numpy()
+    # sklearn flips the sign of LIBSVM's decision value for a two-class problem
+    return [-dec[toff[f]:toff[f + 1]] for f in range(len(tests))]
+
+
+def crossValidate(args_svm, K, n_pseqs, n_nseqs):
+    """Same arguments and result as the reference's `crossValidate` (scripts/gkmsvm.py:127-176)
+    with `K` a symmetric torch CUDA matrix: (mean AUC, std AUC) over ncv x repeats folds."""
+    from sklearn.metrics import roc_auc_score
+    from sklearn.model_selection import StratifiedKFold
+    regularization, precision, shrinking, _cache, ncv, repeats, fast_estimation, random_seeds = args_svm[:8]
+    if fast_estimation != 0:
+        raise NotImplementedError("fast AUC estimation is dead code in the reference (its regressor is never loaded)")
+    if shrinking:
+        logging.info("the GPU solver does not shrink: same optimum as --shrinking 1 up to the tolerance")
+    if random_seeds is not None and random_seeds < 0:
+        random_seeds = None
+    seqids = ["p%4d" % i for i in range(n_pseqs)] + ["n%4d" % i for i in range(n_nseqs)]
+    y = np.concatenate((np.repeat(1, n_pseqs), np.repeat(0, n_nseqs)))
+    trains, tests = [], []
+    for _ in range(repeats):
+        folds = StratifiedKFold(n_splits=ncv, shuffle=True, random_state=random_seeds)
+        for train, test in folds.split(seqids, y):
+            trains.append(train)
+            tests.append(test)
+    logging.info("cross-validation on the GPU: %d folds", len(trains))
+    sol, handles = train_folds(K, trains, y, regularization, precision)
+    scores = decision_values(K, handles, tests)
+    aucs = []
+    for f, (test, score) in enumerate(zip(tests, scores)):
+        auc = roc_auc_score(y[test], score)
+        nu = np.sum(sol.alpha[f]) / len(trains[f])
+        logging.info("SVC training and validation; nu = %.3f, AUC = %.3f, %d iterations", nu, auc, abs(int(sol.iters[f])))
+        aucs.append(auc)
+    logging.info("done cross-validation.")
+    return (np.mean(aucs), np.std(aucs))

@@ -23,14 +23,14 @@ def dev(built):
 def _declared_functions(header):
     txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
-    return sorted(set(re.findall(r"\b(gkm(?:hip)?_[a-z0-9_]+)\s*\(", txt)))
+    return sorted(set(re.findall(r"\b(gkm(?:hip|svm)?_[a-z0-9_]+)\s*\(", txt)))
 
 
-@pytest.mark.parametrize("header", ["gkmkern_pylib.h", "gkm_hip.h"])
-def test_every_declared_symbol_is_exported(dev, header):
+@pytest.mark.parametrize("header,least", [("gkmkern_pylib.h", 8), ("gkm_hip.h", 8), ("gkm_svm.h", 3)])
+def test_every_declared_symbol_is_exported(dev, header, least):
     lib = ctypes.CDLL(dev.lib_path())
     names = _declared_functions(header)
-    assert len(names) >= 8
+    assert len(names) >= least
     for name in names:
         assert hasattr(lib, name), "%s declared in include/%s but not exported" % (name, header)
 

@@ -1,0 +1,124 @@
+"""GPU-resident C-SVC (gkmqc_amd/csrc/gkm_svm.hip, include/gkm_svm.h) against
+scikit-learn's LIBSVM -- the solver the reference calls (scripts/gkmsvm.py:104-125).  The bar is
+bit-identity of everything the solver returns (support set, dual coefficients, intercept, decision
+values), which implies identical AUC; the cross-validation is also checked against the AUCs the
+reference's own module produced (tests/golden/gkmsvm_expected.json)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import helpers
+
+pytestmark = pytest.mark.gpu
+
+EXPECTED = json.load(open(os.path.join(helpers.GOLDEN, "gkmsvm_expected.json")))
+POS = os.path.join(helpers.GOLDEN, "motif_pos.fa")
+NEG = os.path.join(helpers.GOLDEN, "motif_neg.fa")
+
+
+def _rbf_matrix(n, dim, seed, dup=0):
+    """A positive-definite test kernel with class structure; `dup` duplicated points force exact
+    ties in the working-set selection."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, dim))
+    X[: n // 2] += 0.6
+    if dup:
+        X[n - dup:] = X[:dup]
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    K = np.exp(-d2 / (2.0 * dim))
+    return np.maximum(K, K.T)
+
+
+def _compare_with_sklearn(K, n_first, trains, tests, C, tol):
+    import torch
+    from sklearn.svm import SVC
+    from gkmqc_amd import svmcv
+    n = K.shape[0]
+    y = np.concatenate((np.repeat(1, n_first), np.repeat(0, n - n_first)))
+    Kd = torch.from_numpy(K).cuda()
+    sol, handles = svmcv.train_folds(Kd, trains, y, C, tol)
+    scores = svmcv.decision_values(Kd, handles, tests)
+    for f, (train, test) in enumerate(zip(trains, tests)):
+        sv = SVC(kernel="precomputed", C=C, tol=tol, shrinking=False, cache_size=512)
+        sv.fit(K[train][:, train], y[train])
+        coef, support = sol.dual_coef(f)
+        # sklearn's support_ are positions in `train`
+        pos_in_train = {g: p for p, g in enumerate(train)}
+        got_support = np.array([pos_in_train[g] for g in support])
+        assert sol.iters[f] > 0
+        assert np.array_equal(got_support, sv.support_), "fold %d: support set differs" % f
+        assert np.array_equal(coef, sv.dual_coef_[0]), "fold %d: max |diff| %g" % (
+            f, np.abs(coef - sv.dual_coef_[0]).max())
+        assert sol.rho[f] == sv.intercept_[0]
+        want = sv.decision_function(K[test][:, train])
+        assert np.array_equal(scores[f], want), "fold %d: decision values differ by %g" % (
+            f, np.abs(scores[f] - want).max())
+
+
+def _folds(n, n_first, ncv, seed):
+    from sklearn.model_selection import StratifiedKFold
+    y = np.concatenate((np.repeat(1, n_first), np.repeat(0, n - n_first)))
+    sp = StratifiedKFold(n_splits=ncv, shuffle=True, random_state=seed).split(np.zeros(n), y)
+    trains, tests = zip(*sp)
+    return list(trains), list(tests)
+
+
+@pytest.mark.parametrize("n,dim,C,tol,dup", [
+    (200, 6, 1.0, 1e-3, 0),
+    (600, 10, 1.0, 1e-3, 0),
+    (600, 10, 0.05, 1e-3, 0),      # most alphas at the upper bound
+    (400, 4, 100.0, 1e-4, 0),      # few bounded, many iterations
+    (300, 5, 1.0, 1e-3, 40),       # duplicated samples: exact ties in the selection
+    (2600, 12, 1.0, 1e-3, 0),      # more samples than threads (several per thread)
+])
+def test_solver_is_bit_identical_to_sklearn(built, n, dim, C, tol, dup):
+    K = _rbf_matrix(n, dim, seed=n + dim, dup=dup)
+    trains, tests = _folds(n, n // 2, 3, seed=1)
+    _compare_with_sklearn(K, n // 2, trains, tests, C, tol)
+
+
+def test_unbalanced_and_tiny_folds(built):
+    K = _rbf_matrix(90, 3, seed=5)
+    trains, tests = _folds(90, 12, 4, seed=3)
+    _compare_with_sklearn(K, 12, trains, tests, 1.0, 1e-3)
+    # a two-sample problem
+    _compare_with_sklearn(K, 12, [np.array([0, 50])], [np.array([1, 2, 60])], 1.0, 1e-3)
+
+
+@pytest.mark.parametrize("name", sorted(EXPECTED))
+def test_gkm_matrix_solver_and_cv_match_reference(built, name):
+    """gkm matrix computed on the GPU, left in HBM, cross-validated there: per-fold bit-identity with
+    sklearn and the AUC mean/std of the reference's module."""
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED[name]
+    a = list(case["args_gkm"])
+    a[7], a[8] = POS, NEG
+    Kd, n_pos, n_neg = gkmsvm.computeGkmKernel(a, resident=True)
+    assert Kd.is_cuda
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), Kd, n_pos, n_neg)
+    assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
+    C, tol = case["args_svm"][0], case["args_svm"][1]
+    trains, tests = _folds(n_pos + n_neg, n_pos, case["args_svm"][4], seed=case["args_svm"][7])
+    _compare_with_sklearn(Kd.cpu().numpy(), n_pos, trains, tests, C, tol)
+
+
+def test_main_uses_the_gpu_solver(built, tmp_path):
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    out = str(tmp_path / "run_gpu")
+    for solver in ("gpu", "sklearn"):
+        auc, std = gkmsvm.main(["-p", POS, "-n", NEG, "-w", out, "-s", "7", "-v", "0", "-t", "4", "-L", "10", "-k", "6",
+                                "-d", "3", "-r", "2", "--svm-solver", solver])
+        assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
+
+
+def test_bad_arguments_fail_loudly(built):
+    import torch
+    from gkmqc_amd import svmcv
+    K = torch.eye(8, dtype=torch.float64)
+    with pytest.raises(svmcv.SvmError):
+        svmcv.train_folds(K, [np.arange(8)], np.array([1] * 4 + [0] * 4))        # not on the GPU
+    with pytest.raises(svmcv.SvmError):
+        svmcv.train_folds(K.cuda(), [np.arange(4)], np.array([1] * 4 + [0] * 4))  # one class only
