@@ -121,8 +121,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # GKM_BENCH_FORCE_DIST=1: take the sharded path (process group, slabs, all-gather, permutation)
+    # even with one rank -- exercises the real RCCL backend on a one-GPU box
+    dist_on = world > 1 or os.environ.get("GKM_BENCH_FORCE_DIST") == "1"
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
@@ -134,7 +138,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if dist_on:
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -152,11 +156,11 @@ def main():
 
     # Row sharding: folded row blocks per rank; with more than one rank the rank's rows are cut
     # into interleaved chunks so that the RCCL all-gather of one chunk overlaps the kernel of the next.
-    chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4"))) if world > 1 else 1
+    chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4"))) if dist_on else 1
     parts, pc = sharding.chunked_layout(n, world, rank, chunks)
     full = torch.zeros((n, n), dtype=torch.float64, device=dev)
     sq = torch.zeros(n, dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         slab = torch.zeros((chunks, pc, n), dtype=torch.float64, device=dev)
         gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64, device=dev)
         slot_of_row = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks)).to(dev)
@@ -166,7 +170,7 @@ def main():
             ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream)
 
     def step():
-        if world == 1:
+        if not dist_on:
             compute(0, full.data_ptr(), False)
         else:
             pending = []
@@ -184,7 +188,7 @@ def main():
         ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
 
     def barrier():
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -196,7 +200,7 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -209,7 +213,7 @@ def main():
         for c in range(chunks):
             if not len(parts[c]):
                 continue
-            compute(c, full.data_ptr() if world == 1 else slab[c].data_ptr(), world > 1)
+            compute(c, slab[c].data_ptr() if dist_on else full.data_ptr(), dist_on)
             torch.cuda.synchronize(dev)
             ms += ctx.last_kernel_ms()
             comparisons += ctx.last_comparisons()   # 2 n_a n_j summed over this rank's (a, j<=a) pairs
@@ -247,7 +251,7 @@ def main():
         "config": {"workload": "configs[1]: %d pos + %d neg x %d bp iid ACGT (splitmix64 seeds 1/2), kernel type %d, "
                                "L=%d k=%d d=%d, M=50 H=50; full lower-triangular Gram matrix + normalisation"
                                % (args.n_pos, args.n_neg, args.length, args.kernel_type, args.L, args.k, args.d),
-                   "n_sequences": n, "row_sharding": ("folded row blocks in %d interleaved chunks, RCCL all-gather overlapped with the next chunk" % chunks) if world > 1 else "single GPU",
+                   "n_sequences": n, "row_sharding": ("folded row blocks in %d interleaved chunks, RCCL all-gather overlapped with the next chunk" % chunks) if dist_on else "single GPU",
                    "kernel": kname},
     }
     if rank == 0:
@@ -271,7 +275,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.L, args.k, args.d, args.kernel_type)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
