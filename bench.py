@@ -232,6 +232,9 @@ def main():
         print("rank %d: assembled matrix identical to single-GPU matrix: %s" % (rank, same), file=sys.stderr, flush=True)
         assert same
 
+    shape = (args.n_pos, args.n_neg, args.length, lr, args.L, args.k, args.d)
+    WORKLOAD_LABEL = {(5000, 5000, 300, None, 11, 7, 3): "configs[1]", (200, 200, 300, None, 10, 6, 3): "configs[0]",
+                      (10000, 10000, 300, None, 11, 7, 3): "configs[2]"}.get(shape, "custom")
     pairs = n * (n - 1) / 2
     sec_per_step = elapsed / args.steps
     out = {
@@ -248,7 +251,7 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": "configs[1]: %d pos + %d neg x %d bp iid ACGT (splitmix64 seeds 1/2), kernel type %d, "
+        "config": {"workload": WORKLOAD_LABEL + ": %d pos + %d neg x %d bp iid ACGT (splitmix64 seeds 1/2), kernel type %d, "
                                "L=%d k=%d d=%d, M=50 H=50; full lower-triangular Gram matrix + normalisation"
                                % (args.n_pos, args.n_neg, args.length, args.kernel_type, args.L, args.k, args.d),
                    "n_sequences": n, "row_sharding": ("folded row blocks in %d interleaved chunks, RCCL all-gather overlapped with the next chunk" % chunks) if dist_on else "single GPU",
