@@ -305,9 +305,9 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     return x;
 }
 
-constexpr int BS_SBUF = 448;  /* wave-wide list of compacted hit words */
-constexpr int BS_SPAD = 512;  /* list stride in LDS (>= BS_SBUF + 1 trash slot, multiple of 64) */
-constexpr int BS_TRIP = 128;  /* words resolved per trip (2 per lane) */
+constexpr int BS_GRP = 5;     /* hit words per list record: the lanes are compacted once per BS_GRP words */
+constexpr int BS_CAP = 192;   /* records the wave-wide hit list (a ring) holds; multiple of 64: merged LDS stores */
+constexpr int BS_TRIP = 128;  /* records resolved per trip (2 per lane) */
 #ifndef GKM_BS_DU
 #define GKM_BS_DU 3 /* A/B on config 2: 2 -> 114.9 ms, 3 -> 114.8, 5 -> 118.0, 10 -> 117.9 */
 #endif
@@ -334,11 +334,13 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
      * by registers.  The l-mer tables the hit resolution reads stay in global memory (1.2 KB per
      * sequence and strand, L1/L2 resident): keeping LDS small buys the occupancy that hides the
      * latency of the hit path (measured: 301 -> 244 ms on config 2 when the tables left LDS). */
-    /* one array, meta half exactly 512 dwords after the word half: both stores of a push merge
-     * into a single ds_write2st64_b32 */
-    __shared__ uint32_t s_list[2 * BS_SPAD];
-    uint32_t *const s_h = s_list;              /* wave-wide list of hit words (+ trash slot) ...    */
-    uint32_t *const s_meta = s_list + BS_SPAD; /* ... and their origin: w, delta, strand, row lane  */
+    /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
+     * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
+     * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
+     * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
+     * instructions per word out of the hot loop (config 2: 111.6 -> see DESIGN.md §8). */
+    __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
+    uint32_t *const s_meta = s_list + BS_GRP * BS_CAP; /* first word of the group, delta, strand, row lane */
     /* PACKED: lanes may hold several pieces (gkm_pack.h) and a tile up to MAX_ROWS rows.  When no
      * lane of the call holds more than one piece (e.g. every fixed-length data set) the leaner
      * variant runs: one (slot, base) pair per lane, at most 64 rows per tile, 3 KB less LDS
@@ -348,8 +350,12 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
     __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
     __shared__ uint32_t lpiece[64 * NP * 2];     /* row slot, l-mer table base per piece       */
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
-    constexpr int CHK = 5; /* the list is checked every CHK words (at most 64 * CHK new entries) */
-    static_assert(BS_SBUF >= BS_TRIP + 64 * CHK, "hit list too small");
+    static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
+    /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
+     * every group (at most 64 new records), a trip pops BS_TRIP records before it appends at most as
+     * many again: the ring never holds more than BS_TRIP + 63 records. */
+    static_assert(BS_CAP >= BS_TRIP + 64 && BS_CAP % 64 == 0, "hit list too small");
+    auto ring = [](uint32_t x) { return min(x, x - (uint32_t)BS_CAP); }; /* x mod BS_CAP for x < 2 BS_CAP */
     static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
-        int s_n = 0; /* words in the hit list (wave-uniform) */
+        int s_n = 0, s_hd = 0; /* records in the hit ring and its head (wave-uniform) */
 
         /* one hit record -> accl[m][row slot] += wa * wb.  The lane and bit row of the hit name the
          * piece (gkm_pack.h), the piece names the row slot and where its l-mers sit in the table */
@@ -409,63 +415,57 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
             if (hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
-        /* Resolve the hit list in FULL trips of 2 x 64 words with every lane busy: each word gives
-         * up its lowest hit bit, what is left of a multi-hit word is appended again.  Fewer than one
-         * trip's worth of words is moved to the front and waits; the last call of a column (final)
-         * empties the list. */
+        /* Resolve the hit list in FULL trips of 2 x 64 records with every lane busy: each record gives
+         * up the lowest hit bit of its first non-empty word, what is left of a multi-hit record is
+         * appended again.  Fewer than one trip's worth of records waits in the ring; the last call of
+         * a column (final) empties it. */
         auto trips = [&](bool final) {
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
-            int hd = 0;
-            while (s_n - hd >= BS_TRIP || (final && s_n - hd > 0)) {
-                const int c = min(s_n - hd, BS_TRIP);
-                uint32_t left[2], meta[2];
+            while (s_n >= BS_TRIP || (final && s_n > 0)) {
+                const int c = min(s_n, BS_TRIP);
+                uint32_t h[2][BS_GRP], meta[2], left[2];
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const int i = k * 64 + lane;
-                    const uint32_t h = (i < c) ? s_h[hd + i] : 0u;
-                    meta[k] = s_meta[min(hd + i, BS_SBUF - 1)];
-                    if (h) resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
-                    left[k] = h & (h - 1u);
+                    const uint32_t at = ring((uint32_t)(s_hd + i));
+#pragma unroll
+                    for (int g = 0; g < BS_GRP; g++) h[k][g] = (i < c) ? s_list[g * BS_CAP + at] : 0u;
+                    meta[k] = s_meta[at];
+                    /* first non-empty word of the record (scanned from the last word down) */
+                    uint32_t hw = h[k][BS_GRP - 1], sel = BS_GRP - 1;
+#pragma unroll
+                    for (int g = BS_GRP - 2; g >= 0; g--) {
+                        const bool take = h[k][g] != 0u;
+                        hw = take ? h[k][g] : hw;
+                        sel = take ? (uint32_t)g : sel;
+                    }
+                    if (hw) resolve((meta[k] + sel) | ((uint32_t)__builtin_ctz(hw) << 24));
+                    const uint32_t cleared = hw & (hw - 1u);
+#pragma unroll
+                    for (int g = 0; g < BS_GRP; g++) h[k][g] = sel == (uint32_t)g ? cleared : h[k][g];
+                    left[k] = h[k][0];
+#pragma unroll
+                    for (int g = 1; g + 1 < BS_GRP; g += 2) left[k] = lop3<TT_OR3>(left[k], h[k][g], h[k][g + 1]);
+                    if (BS_GRP % 2 == 0) left[k] |= h[k][BS_GRP - 1];
                 }
-                hd += c;
+                s_hd = (int)ring((uint32_t)(s_hd + c));
+                s_n -= c;
 #pragma unroll
                 for (int k = 0; k < 2; k++) {
                     const unsigned long long more = __ballot(left[k] != 0u);
                     if (more) {
-                        const int at = s_n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                        if (left[k] != 0u && at < BS_SBUF) {
-                            s_h[at] = left[k];
+                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                        if (left[k] != 0u) {
+                            const uint32_t at = ring(ring((uint32_t)(s_hd + s_n)) + rank);
+#pragma unroll
+                            for (int g = 0; g < BS_GRP; g++) s_list[g * BS_CAP + at] = h[k][g];
                             s_meta[at] = meta[k];
-                        } else if (left[k] != 0u) { /* list full: finish this word here */
-                            uint32_t h = left[k];
-                            while (h) {
-                                resolve(meta[k] | ((uint32_t)__builtin_ctz(h) << 24));
-                                h &= h - 1u;
-                            }
                         }
-                        s_n = min(s_n + (int)__popcll(more), BS_SBUF);
+                        s_n += (int)__popcll(more);
                     }
                 }
             }
-            const int rem = s_n - hd; /* < BS_TRIP <= hd whenever hd > 0: source and target disjoint */
-            if (hd > 0 && rem > 0) {
-                uint32_t th[2], tm[2];
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    const int i = min(hd + k * 64 + lane, BS_SBUF - 1);
-                    th[k] = s_h[i];
-                    tm[k] = s_meta[i];
-                }
-#pragma unroll
-                for (int k = 0; k < 2; k++) {
-                    if (k * 64 + lane < rem) {
-                        s_h[k * 64 + lane] = th[k];
-                        s_meta[k * 64 + lane] = tm[k];
-                    }
-                }
-            }
-            s_n = rem;
         };
 
         for (int strand = 0; strand < 2; strand++) {
@@ -492,29 +492,32 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
                         window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, (const uint32_t *)nullptr, hit);
                         const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand);
 #pragma unroll
-                        for (int w = 0; w < W; w++) {
-                            const uint32_t h = hit[w];
+                        for (int w0 = 0; w0 < W; w0 += BS_GRP) {
                             if ((VARIANT & 3) == 1) {
-                                accl[lane] += __popc(h);
-                            } else {
-                                /* wave-level compaction at the source: the lanes with a hit in this
-                                 * word append (word, origin) to the list at tail + their rank among
-                                 * the hit lanes (ballot + mbcnt); the others store to a trash slot,
-                                 * so there is no divergent control flow */
-                                const unsigned long long mask = __ballot(h != 0u);
-                                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
-                                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                                if (h != 0u) { /* EXEC-masked stores: no select, no trash slot needed */
-                                    const uint32_t at = ((uint32_t)rank << 2) + ((uint32_t)s_n << 2);
-                                    *(uint32_t *)((char *)s_h + at) = h;
-                                    *(uint32_t *)((char *)s_meta + at) = vbase | (uint32_t)w;
-                                }
-                                s_n += (int)__popcll(mask);
-                                if (w % CHK == CHK - 1 || w == W - 1) {
-                                    if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
-                                    else if (s_n >= BS_TRIP) trips(false);
-                                }
+#pragma unroll
+                                for (int g = 0; g < BS_GRP; g++) accl[lane] += __popc(hit[w0 + g]);
+                                continue;
                             }
+                            /* wave-level compaction at the source, once per group of BS_GRP words: the
+                             * lanes with a hit in the group append (words, origin) to the list at tail
+                             * + their rank among the hit lanes (ballot + mbcnt); EXEC-masked stores, no
+                             * divergent control flow */
+                            uint32_t any = hit[w0];
+#pragma unroll
+                            for (int g = 1; g + 1 < BS_GRP; g += 2) any = lop3<TT_OR3>(any, hit[w0 + g], hit[w0 + g + 1]);
+                            if (BS_GRP % 2 == 0) any |= hit[w0 + BS_GRP - 1];
+                            const unsigned long long mask = __ballot(any != 0u);
+                            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (any != 0u) {
+                                char *const at = (char *)s_list + (ring((uint32_t)rank + ring((uint32_t)(s_hd + s_n))) << 2);
+#pragma unroll
+                                for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
+                                *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;
+                            }
+                            s_n += (int)__popcll(mask);
+                            if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
+                            else if (s_n >= BS_TRIP) trips(false);
                         }
                     }
                 }
