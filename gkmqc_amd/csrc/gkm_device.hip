@@ -319,9 +319,10 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 /*
  * One wavefront = 64 row segments (one per lane) x a chunk of `cj` column sequences.
  * For every column strand the wave sweeps all T cyclic shifts; per shift each lane
- * evaluates 32*W l-mer window comparisons with ~40 integer ops per 32 (gkm_bitslice.h).
- * Hit words are parked in a per-lane LDS queue and turned into weighted profile counts
- * in batches, so the hot loop has no data-dependent control flow besides the push.
+ * evaluates 32*W l-mer window comparisons with ~17 VALU instructions per 32 (gkm_bitslice.h).
+ * Hit words are parked, compacted over the lanes, in a wave-wide LDS ring of records and turned
+ * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
+ * control flow besides the push.
  */
 template <int W, int L, int D, bool PACKED, int VARIANT = 0>
 __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs
      * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
      * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
      * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
-     * instructions per word out of the hot loop (config 2: 111.6 -> see DESIGN.md §8). */
+     * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
     __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
     uint32_t *const s_meta = s_list + BS_GRP * BS_CAP; /* first word of the group, delta, strand, row lane */
     /* PACKED: lanes may hold several pieces (gkm_pack.h) and a tile up to MAX_ROWS rows.  When no
