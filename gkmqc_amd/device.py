@@ -79,6 +79,10 @@ def load():
     L.gkm_problem_seqlen.argtypes = (vp, i32)
     L.gkm_problem_codes.restype = ctypes.POINTER(ctypes.c_uint8)
     L.gkm_problem_codes.argtypes = (vp, i32)
+    L.gkm_problem_offsets.restype = ctypes.POINTER(ctypes.c_int64)
+    L.gkm_problem_offsets.argtypes = (vp,)
+    L.gkm_problem_all_codes.restype = ctypes.POINTER(ctypes.c_uint8)
+    L.gkm_problem_all_codes.argtypes = (vp,)
     for name in ("gkm_problem_invalid_chars", "gkm_problem_truncated"):
         getattr(L, name).restype = ctypes.c_long
         getattr(L, name).argtypes = (vp,)
@@ -156,20 +160,42 @@ def distance_weights(kernel_type, max_n, M=50, H=50.0):
     return np.ascontiguousarray(position_weights(kernel_type, 2 * dmax + 1, M, H)[dmax:])
 
 
+class FlatSequences:
+    """All sequences of a problem back to back: `codes` (uint8, 0..3) and `off` (int64, n+1).
+    Behaves like a list of per-sequence arrays (views) where one is needed."""
+
+    def __init__(self, codes, off):
+        self.codes, self.off = codes, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        return self.codes[self.off[i]:self.off[i + 1]]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 def read_problem(posfile, negfile):
-    """FASTA pair -> (list of uint8 base-code arrays, n_pos, n_invalid_chars, n_truncated)."""
+    """FASTA pair -> (FlatSequences of base codes, n_pos, n_invalid_chars, n_truncated).
+    Two bulk copies out of the C reader, no per-sequence work in Python."""
     L = load()
     h = L.gkm_problem_read(os.fsencode(posfile), os.fsencode(negfile))
     if not h:
         raise GkmError("cannot read %s / %s" % (posfile, negfile))
     try:
         n = L.gkm_problem_size(h)
-        seqs = []
-        for i in range(n):
-            ln = L.gkm_problem_seqlen(h, i)
-            ptr = L.gkm_problem_codes(h, i)
-            seqs.append(np.ctypeslib.as_array(ptr, shape=(ln,)).copy() if ln else np.zeros(0, np.uint8))
-        return seqs, L.gkm_problem_npos(h), L.gkm_problem_invalid_chars(h), L.gkm_problem_truncated(h)
+        off = np.ctypeslib.as_array(L.gkm_problem_offsets(h), shape=(n + 1,)).copy()
+        total = int(off[-1])
+        codes = (np.ctypeslib.as_array(L.gkm_problem_all_codes(h), shape=(total,)).copy() if total
+                 else np.zeros(0, np.uint8))
+        return (FlatSequences(codes, off), L.gkm_problem_npos(h), L.gkm_problem_invalid_chars(h),
+                L.gkm_problem_truncated(h))
     finally:
         L.gkm_problem_free(h)
 
@@ -222,12 +248,17 @@ class GramContext:
         self._chk(self.lib.gkmhip_set_kernel(self.handle, which), "gkmhip_set_kernel")
 
     def set_sequences(self, seqs, stream=0):
-        """seqs: list of uint8 arrays of base codes 0..3."""
+        """seqs: list of uint8 arrays of base codes 0..3, or a FlatSequences."""
         n = len(seqs)
-        lens = np.array([len(s) for s in seqs], dtype=np.int64)
-        off = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(lens, out=off[1:])
-        codes = np.concatenate(seqs).astype(np.uint8) if n else np.zeros(0, np.uint8)
+        if isinstance(seqs, FlatSequences):
+            off = np.ascontiguousarray(seqs.off, dtype=np.int64)
+            codes = np.ascontiguousarray(seqs.codes, dtype=np.uint8)
+            lens = np.diff(off)
+        else:
+            lens = np.array([len(s) for s in seqs], dtype=np.int64)
+            off = np.zeros(n + 1, dtype=np.int64)
+            np.cumsum(lens, out=off[1:])
+            codes = np.concatenate(seqs).astype(np.uint8) if n else np.zeros(0, np.uint8)
         if (lens < self.L).any():
             raise GkmError("a sequence is shorter than L")
         wd = None

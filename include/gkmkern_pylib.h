@@ -78,6 +78,8 @@ int gkm_problem_size(const gkm_problem *p);     /* n_pos + n_neg */
 int gkm_problem_npos(const gkm_problem *p);
 int gkm_problem_seqlen(const gkm_problem *p, int i);
 const uint8_t *gkm_problem_codes(const gkm_problem *p, int i); /* 0..3 = A,C,G,T */
+const int64_t *gkm_problem_offsets(const gkm_problem *p);      /* [n+1] offsets into the concatenated codes */
+const uint8_t *gkm_problem_all_codes(const gkm_problem *p);    /* all sequences back to back (gkmhip_set_sequences) */
 long gkm_problem_invalid_chars(const gkm_problem *p);          /* mapped to 'A' */
 long gkm_problem_truncated(const gkm_problem *p);              /* cut at 2047 nt */
 

@@ -1,0 +1,63 @@
+"""Where the time of the GPU-resident pipeline (gkmqc_amd.gkmsvm: FASTA -> matrix -> CV) goes.
+python tools/pipeline_profile.py [--n-pos 5000 --n-neg 5000]"""
+import argparse
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n-pos", type=int, default=5000)
+    ap.add_argument("--n-neg", type=int, default=5000)
+    ap.add_argument("--length", type=int, default=300)
+    a = ap.parse_args()
+    import torch
+    from gkmqc_amd import device, gkmsvm, svmcv, synth
+    tmp = tempfile.mkdtemp()
+    pos, neg = os.path.join(tmp, "p.fa"), os.path.join(tmp, "n.fa")
+    synth.write_problem(pos, neg, a.n_pos, a.n_neg, a.length)
+    torch.zeros(1, device="cuda")
+    for rep in range(3):
+        t = [time.perf_counter()]
+        seqs, n_pos, _, _ = device.read_problem(pos, neg)
+        t.append(time.perf_counter())
+        ctx = device.GramContext(4, 11, 7, 3, 50, 50.0, 1.0, 0)
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.set_sequences(seqs, stream)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        n = len(seqs)
+        G = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+        sq = torch.zeros(n, dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        ctx.gram_rows(np.arange(n), G.data_ptr(), n, None, n, False, stream)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        ctx.normalize(G.data_ptr(), n, sq.data_ptr(), False, stream)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        K = torch.maximum(G, G.T)
+        torch.cuda.synchronize()
+        t.append(time.perf_counter())
+        ctx.close()
+        t.append(time.perf_counter())
+        auc = svmcv.crossValidate([1.0, 0.001, 0, 512, 5, 1, 0, 7, 1], K, n_pos, n - n_pos)
+        t.append(time.perf_counter())
+        names = ["read_problem", "ctx+set_sequences", "alloc", "gram_rows", "normalize", "maximum(K,K.T)", "close", "cv"]
+        print("rep %d: " % rep + "  ".join("%s %.1f ms" % (nm, (t[i + 1] - t[i]) * 1e3) for i, nm in enumerate(names))
+              + "  total %.1f ms" % ((t[-1] - t[0]) * 1e3))
+        t0 = time.perf_counter()
+        gkmsvm.main(["-p", pos, "-n", neg, "-w", os.path.join(tmp, "out"), "-s", "7", "-v", "0", "-t", "4", "-L", "11",
+                     "-k", "7", "-d", "3"])
+        print("        gkmsvm.main end to end %.1f ms" % ((time.perf_counter() - t0) * 1e3))
+
+
+if __name__ == "__main__":
+    main()
