@@ -40,7 +40,7 @@ static int svm_fail(const char *what, hipError_t e)
         if (e_ != hipSuccess) return svm_fail(#expr, e_); \
     } while (0)
 
-constexpr int SVM_MAX_R = 16;      /* samples per thread */
+constexpr int SVM_MAX_R = 16;      /* samples per thread at the largest size */
 constexpr int SVM_MAX_THREADS = 1024;
 constexpr int SVM_MAX_L = SVM_MAX_THREADS * SVM_MAX_R;
 constexpr double SVM_TAU = 1e-12;
