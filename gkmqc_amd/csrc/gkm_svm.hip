@@ -13,7 +13,7 @@
  *   D  gather Q_j, G_k += Q_ik dalpha_i + Q_jk dalpha_j
  * alpha and G live in registers; the kernel matrix is only read (two row gathers per iteration).
  * Measured (MI355X, 5 folds of 8000 samples from the 10 000 x 10 000 headline matrix, 10.4 k
- * iterations each): 0.13 s for the whole cross-validation, ~27 k cycles per iteration, bound by
+ * iterations each): 0.10 s for the whole cross-validation, ~22 k cycles per iteration, bound by
  * the instruction issue of the one CU a fold runs on (scikit-learn, 5 processes: 0.95 s).
  * -DSVM_PROF prints the per-phase cycle counts.
  */
@@ -156,7 +156,7 @@ __global__ void k_diag(const double *__restrict__ K, int64_t ld, int n, double *
  * its payload in LDS, every thread then picks the block winner from the T/64 records and does
  * the (scalar) two-variable update redundantly, so no third exchange is needed.
  */
-template <int T, int SVM_R>
+template <int T, int SVM_R, bool TAB>
 __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t ld, const double *__restrict__ diag,
                                            const SvmProb *probs, double C, double eps, int max_iter)
 {
@@ -167,16 +167,32 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     const SvmProb p = probs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = p.l, n0 = p.n0;
 
-    int gidx[SVM_R];
-    double qd[SVM_R], al[SVM_R], G[SVM_R];
+    /* TAB: the samples' matrix indices and kernel diagonal live in (dynamic) LDS instead of
+     * registers -- 48 VGPRs less at 16 samples per thread, which is what keeps alpha and G from
+     * spilling to scratch (12 bytes per sample: up to 8192 samples in 96 KB of the CU's 160 KB) */
+    extern __shared__ double dyn_lds[];
+    double *const qd_s = dyn_lds;
+    int *const gidx_s = (int *)(dyn_lds + T * SVM_R);
+    int gidx[TAB ? 1 : SVM_R];
+    double qd[TAB ? 1 : SVM_R], al[SVM_R], G[SVM_R];
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
-        gidx[r] = k < l ? p.idx[k] : 0;
-        qd[r] = k < l ? diag[gidx[r]] : 0.0;
+        const int g = k < l ? p.idx[k] : 0;
+        const double dg = k < l ? diag[g] : 0.0;
+        if (TAB) {
+            gidx_s[k] = g;
+            qd_s[k] = dg;
+        } else {
+            gidx[r] = g;
+            qd[r] = dg;
+        }
         al[r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1 */
         G[r] = -1.0;
     }
+    if (TAB) __syncthreads();
+    auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : gidx[TAB ? 0 : r]; };
+    auto QD = [&](int r) { return TAB ? qd_s[tid + r * T] : qd[TAB ? 0 : r]; };
 
 #ifdef SVM_PROF
     long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
@@ -211,7 +227,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const int rr = (bk - tid) / T;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr) candA[wave] = {bv, al[r], G[r], qd[r], 0.0, bk, gidx[r]};
+                if (r == rr) candA[wave] = {bv, al[r], G[r], TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
         /* the NW wave winners: one per lane of a row, DPP selection, then one broadcast read */
@@ -224,8 +240,8 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         if (i < 0) break;
         const double Gmax = ci.v;
         const double yi = i < n0 ? 1.0 : -1.0;
-        const double *Ki = K + (int64_t)ci.g * ld;
-        const double QDi = ci.qd;
+        const double *Ki = K + (int64_t)(TAB ? gidx_s[i] : ci.g) * ld;
+        const double QDi = TAB ? qd_s[i] : ci.qd;
 
         /* ---- second index: argmin over I_low of -(grad_diff^2)/quad, and Gmax2 ---- */
         float qik[SVM_R]; /* Q_ik is a float in LIBSVM (Qfloat): half the registers */
@@ -233,7 +249,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         double mv = INFINITY, g2max = -INFINITY;
         int mk = -1;
 #pragma unroll
-        for (int r = 0; r < SVM_R; r++) kik[r] = Ki[gidx[r]]; /* lanes past l read column 0 */
+        for (int r = 0; r < SVM_R; r++) kik[r] = Ki[GI(r)]; /* lanes past l read column 0 */
         /* Q_ik = (float)(y_i y_k K_ik) = +-(float)K_ik, and 2 y_i Q_ik = +-2 (float)K_ik with the sign
          * of y_k, so LIBSVM's two quad_coef expressions are both (QD_i + QD_k) - 2 (float)K_ik, bit
          * for bit; the loop is branch-free (selects), one IEEE division per sample */
@@ -248,7 +264,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const double gs = pos ? G[r] : -G[r];
             g2max = (in_low & (gs > g2max)) ? gs : g2max;
             const double grad_diff = Gmax + gs;
-            const double quad = (QDi + qd[r]) - 2.0 * (double)kf;
+            const double quad = (QDi + QD(r)) - 2.0 * (double)kf;
             const double od = -(grad_diff * grad_diff) / (quad > 0.0 ? quad : SVM_TAU);
             const bool take = in_low & (grad_diff > 0.0) & (od <= mv);
             mv = take ? od : mv;
@@ -264,7 +280,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const int rr = (mk - tid) / T;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr) candB[wave] = {mv, al[r], G[r], qd[r], (double)qik[r], mk, gidx[r]};
+                if (r == rr) candB[wave] = {mv, al[r], G[r], TAB ? 0.0 : qd[TAB ? 0 : r], (double)qik[r], mk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
         wv = candB[lane & (NW - 1)].v;
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 
         /* ---- the two-variable sub-problem, LIBSVM's clipping order (every thread, same result) ---- */
         const double yj = j < n0 ? 1.0 : -1.0;
-        const double Qij = cj.q, QDj = cj.qd;
+        const double Qij = cj.q, QDj = TAB ? qd_s[j] : cj.qd;
         double ai = ci.alpha, aj = cj.alpha;
         const double old_i = ai, old_j = aj;
         if (yi != yj) {
@@ -320,10 +336,10 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         const double dai = ai - old_i, daj = aj - old_j;
 
         /* ---- gradient; the owners store the new alpha ---- */
-        const double *Kj = K + (int64_t)cj.g * ld;
+        const double *Kj = K + (int64_t)(TAB ? gidx_s[j] : cj.g) * ld;
         double kj[SVM_R];
 #pragma unroll
-        for (int r = 0; r < SVM_R; r++) kj[r] = Kj[gidx[r]];
+        for (int r = 0; r < SVM_R; r++) kj[r] = Kj[GI(r)];
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) { /* (lanes past l update a gradient nobody reads) */
             const int k = tid + r * T;
@@ -457,22 +473,26 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
         if (maxl <= 256 * 4) { T = 256; R = 4; }
         else if (maxl <= 512 * 4) { T = 512; R = 4; }
         else if (maxl <= 512 * 8) { T = 512; R = 8; }
-        else if (maxl <= 512 * 16) { T = 512; R = 16; } /* 1024x8 spills at 128 VGPRs: 196 vs 130 ms */
+        else if (maxl <= 1024 * 8) { T = 1024; R = 8; } /* (512x16: 113 ms against 99 ms at 8000 samples) */
         else { T = 1024; R = 16; }
     }
-#define SMO_LAUNCH(TT, RR)                                                                                          \
-    if (T == TT && R == RR)                                                                                         \
-        hipLaunchKernelGGL((k_smo<TT, RR>), dim3((unsigned)nprob), dim3(TT), 0, stream, K, ld, diag, dprobs, C, eps, \
-                           max_iter);                                                                               \
-    else
-    SMO_LAUNCH(256, 4)
-    SMO_LAUNCH(512, 4)
-    SMO_LAUNCH(256, 8)
-    SMO_LAUNCH(512, 8)
-    SMO_LAUNCH(1024, 4)
-    SMO_LAUNCH(1024, 8)
-    SMO_LAUNCH(512, 16)
-    SMO_LAUNCH(1024, 16)
+#define SMO_LAUNCH(TT, RR, TB)                                                                                  \
+    if (T == TT && R == RR) {                                                                                   \
+        const size_t dyn = TB ? (size_t)TT * RR * 12 : 0;                                                       \
+        if (dyn > 0)                                                                                            \
+            SVMCHK(hipFuncSetAttribute((const void *)k_smo<TT, RR, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)dyn));                                                              \
+        hipLaunchKernelGGL((k_smo<TT, RR, TB>), dim3((unsigned)nprob), dim3(TT), dyn, stream, K, ld, diag, dprobs, C, \
+                           eps, max_iter);                                                                      \
+    } else
+    SMO_LAUNCH(256, 4, true)
+    SMO_LAUNCH(512, 4, true)
+    SMO_LAUNCH(256, 8, true)
+    SMO_LAUNCH(512, 8, true)
+    SMO_LAUNCH(1024, 4, true)
+    SMO_LAUNCH(1024, 8, true)
+    SMO_LAUNCH(512, 16, true)
+    SMO_LAUNCH(1024, 16, false)
     {
         g_svm_err = "GKM_SVM_SHAPE: unsupported shape";
         (void)hipFree(diag);
