@@ -187,10 +187,15 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             gidx[r] = g;
             qd[r] = dg;
         }
-        al[r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1 */
-        G[r] = -1.0;
+        al[r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1; stored as S = y G (see below) */
+        G[r] = k < n0 ? -1.0 : 1.0;
     }
     if (TAB) __syncthreads();
+    /* The gradient is kept as S_k = y_k G_k and kernel values without LIBSVM's y_i y_k factor: every
+     * use of G and Q in the solver carries the matching sign (-y G in the first selection, y G in
+     * the second and in rho, Q_ik dalpha_i = y_k (float)K_ik (y_i dalpha_i) in the update), negation
+     * and rounding commute, so the arithmetic is LIBSVM's bit for bit with no per-sample sign
+     * selects.  G[] below holds S. */
     auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : gidx[TAB ? 0 : r]; };
     auto QD = [&](int r) { return TAB ? qd_s[tid + r * T] : qd[TAB ? 0 : r]; };
 
@@ -206,7 +211,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         PROF(5)
         /* ---- first index: argmax over I_up of -y G ---- */
         /* (branch-free: k grows with r, so inside a thread "replace on >=" is LIBSVM's tie rule) */
-        double bv = -INFINITY;
+        double ns = INFINITY; /* min S over I_up = -Gmax */
         int bk = -1;
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) {
@@ -214,11 +219,11 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const bool pos = k < n0; /* y = +1 */
             const bool below_C = al[r] < C, above_0 = al[r] > 0.0; /* (bitwise: no branches) */
             const bool in_up = (k < l) & ((pos & below_C) | (!pos & above_0));
-            const double v = pos ? -G[r] : G[r];
-            const bool take = in_up & (v >= bv);
-            bv = take ? v : bv;
+            const bool take = in_up & (G[r] <= ns);
+            ns = take ? G[r] : ns;
             bk = take ? k : bk;
         }
+        double bv = -ns;
         PROF(0)
         wave_select<false>(bv, bk);
         if (bk < 0) {
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const int rr = (bk - tid) / T;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr) candA[wave] = {bv, al[r], G[r], TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
+                if (r == rr) candA[wave] = {bv, al[r], (bk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
         /* the NW wave winners: one per lane of a row, DPP selection, then one broadcast read */
@@ -244,27 +249,26 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         const double QDi = TAB ? qd_s[i] : ci.qd;
 
         /* ---- second index: argmin over I_low of -(grad_diff^2)/quad, and Gmax2 ---- */
-        float qik[SVM_R]; /* Q_ik is a float in LIBSVM (Qfloat): half the registers */
+        float kfi[SVM_R]; /* (float)K_ik: LIBSVM's Qfloat without its sign y_i y_k */
         double kik[SVM_R];
         double mv = INFINITY, g2max = -INFINITY;
         int mk = -1;
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) kik[r] = Ki[GI(r)]; /* lanes past l read column 0 */
-        /* Q_ik = (float)(y_i y_k K_ik) = +-(float)K_ik, and 2 y_i Q_ik = +-2 (float)K_ik with the sign
-         * of y_k, so LIBSVM's two quad_coef expressions are both (QD_i + QD_k) - 2 (float)K_ik, bit
-         * for bit; the loop is branch-free (selects), one IEEE division per sample */
+        /* 2 y_i Q_ik = +-2 (float)K_ik with the sign of y_k, so LIBSVM's two quad_coef expressions are
+         * both (QD_i + QD_k) - 2 (float)K_ik, bit for bit; the loop is branch-free (selects), one IEEE
+         * division per sample */
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) {
             const int k = tid + r * T;
             const bool pos = k < n0;
-            const float kf = (float)kik[r];
-            qik[r] = (yi > 0.0) == pos ? kf : -kf;
+            kfi[r] = (float)kik[r];
             const bool below_C = al[r] < C, above_0 = al[r] > 0.0;
             const bool in_low = (k < l) & ((pos & above_0) | (!pos & below_C));
-            const double gs = pos ? G[r] : -G[r];
+            const double gs = G[r]; /* y_k G_k */
             g2max = (in_low & (gs > g2max)) ? gs : g2max;
             const double grad_diff = Gmax + gs;
-            const double quad = (QDi + QD(r)) - 2.0 * (double)kf;
+            const double quad = (QDi + QD(r)) - 2.0 * (double)kfi[r];
             const double od = -(grad_diff * grad_diff) / (quad > 0.0 ? quad : SVM_TAU);
             const bool take = in_low & (grad_diff > 0.0) & (od <= mv);
             mv = take ? od : mv;
@@ -280,7 +284,9 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const int rr = (mk - tid) / T;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr) candB[wave] = {mv, al[r], G[r], TAB ? 0.0 : qd[TAB ? 0 : r], (double)qik[r], mk, TAB ? 0 : gidx[TAB ? 0 : r]};
+                if (r == rr)
+                    candB[wave] = {mv, al[r], (mk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r],
+                                   (double)((yi > 0.0) == (mk < n0) ? kfi[r] : -kfi[r]), mk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
         wv = candB[lane & (NW - 1)].v;
@@ -340,12 +346,11 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         double kj[SVM_R];
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) kj[r] = Kj[GI(r)];
+        const double ci_ = yi * dai, cj_ = yj * daj;
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) { /* (lanes past l update a gradient nobody reads) */
             const int k = tid + r * T;
-            const float kf = (float)kj[r];
-            const double qjk = (double)((yj > 0.0) == (k < n0) ? kf : -kf);
-            G[r] += (double)qik[r] * dai + qjk * daj;
+            G[r] += (double)kfi[r] * ci_ + (double)(float)kj[r] * cj_;
             al[r] = k == i ? ai : k == j ? aj : al[r];
         }
         PROF(4)
@@ -359,7 +364,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
-        if (k < l) { p.alpha[k] = al[r]; p.grad[k] = G[r]; }
+        if (k < l) { p.alpha[k] = al[r]; p.grad[k] = k < n0 ? G[r] : -G[r]; }
     }
 
     /* rho (LIBSVM calculate_rho).  The mean over the free vectors is summed in index order by one
@@ -371,7 +376,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         if (r * T >= l) break;
         const int k = tid + r * T;
         const double y = k < n0 ? 1.0 : -1.0;
-        double yG = y * G[r];
+        double yG = G[r]; /* S = y G */
         bool is_free = false;
         if (k < l) {
             if (al[r] >= C) {
