@@ -63,6 +63,16 @@ def measured_traffic():
         return None, None
 
 
+def measured_valu_insts():
+    """SQ_INSTS_VALU (wave instructions) per launch of the dominant kernel from the same summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
+    try:
+        return json.load(open(files[-1]))["per_launch"]["SQ_INSTS_VALU"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, L, k, d, kernel_type):
     """The reference's own CPU path (oracle/_ref, unmodified sources built by oracle/Makefile)
     timed on this box's host cores on a bounded sample of the same workload; falls back to
@@ -260,14 +270,20 @@ def main():
     if rank == 0:
         achieved = comparisons * OPS_PER_COMPARISON / (kern_ms * 1e-3) / 1e9
         traffic, traffic_src = (None, None)
+        insts = None
         if world == 1 and (args.n_pos, args.n_neg, args.length, args.L, args.k, args.d, args.kernel_type) == (5000, 5000, 300, 11, 7, 3, 4):
             traffic, traffic_src = measured_traffic()   # PMC numbers were taken on exactly this workload
+            insts = measured_valu_insts()
         out["roofline"] = {
             "bound": "valu",
             "achieved": achieved, "peak": PEAK_INT32_GOPS, "unit": "Gop/s", "frac": achieved / PEAK_INT32_GOPS,
             "traffic": traffic, "traffic_source": traffic_src,
             "kernel": kname, "kernel_ms": kern_ms, "comparisons_per_launch": comparisons,
             "hbm_achieved_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
+            # executed (not algorithmic) VALU work: rocprofv3 SQ_INSTS_VALU x 64 lanes over the live kernel time
+            "executed_valu_Gops": (insts * 64 / (kern_ms * 1e-3) / 1e9) if insts else None,
+            "executed_frac_of_peak": (insts * 64 / (kern_ms * 1e-3) / 1e9 / PEAK_INT32_GOPS) if insts else None,
+            "executed_insts_per_comparison": (insts * 64 / comparisons) if insts else None,
             "note": "This path is integer-VALU bound, neither HBM nor MFMA (SURVEY.md §8(d)); bound says so. "
                     "achieved = ALGORITHMIC ops: 6 int32 ops per l-mer comparison (SURVEY op model) x "
                     "comparisons_per_launch (2 n_a n_j per pair, this rank's pairs) / kernel_ms (HIP events on the "

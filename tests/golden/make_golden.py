@@ -107,83 +107,96 @@ def ref_K(opt, n):
     return kmat, npos
 
 
+# name: n_pos, n_neg, length, length range, kernel type, L, k, d  (BASELINE.json configs[1], [2], [4])
+FULL_CONFIGS = {"c2": (5000, 5000, 300, None, 4, 11, 7, 3),
+                "c3": (10000, 10000, 300, None, 4, 11, 7, 3),
+                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2-full", action="store_true")
+    ap.add_argument("--full", action="append", choices=sorted(FULL_CONFIGS),
+                    help="full-size digest of a BASELINE configuration through the reference (minutes to an hour)")
+    ap.add_argument("--only-full", action="store_true", help="skip the small fixtures")
     args = ap.parse_args()
     if not O.have_ref():
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
 
-    # (i) mismatch weights c_m, bit patterns as hex
-    wt = {}
-    for (t, L, k, d) in WEIGHT_TUPLES:
-        if O.lib().gkmo_check_params(t, L, k, d):
-            continue
-        wt["%d,%d,%d,%d" % (t, L, k, d)] = [float(x).hex() for x in O.ref_weights(t, L, k, d)]
-    json.dump(wt, open(os.path.join(HERE, "mismatch_weights.json"), "w"), indent=0, sort_keys=True)
-
-    # (ii)+(iii) quirks FASTA: lengths, positional weights, sqnorm, int profiles, K
-    pp, pn = write_quirks()
-    out = {}
-    for idx, (t, L, k, d, M, H, g) in enumerate(QUIRK_PARAMS):
-        opt = O.make_opt(t, L, k, d, M, H, g, pp, pn, nthreads=4)
-        r = O.ref_profiles(opt)
-        n = r["n"]
-        K, npos = ref_K(opt, n)
-        tag = "q%d" % idx
-        out[tag + "_params"] = np.array([t, L, k, d, M, H, g], dtype=np.float64)
-        out[tag + "_P"] = r["P"]
-        out[tag + "_sqnorm"] = r["sqnorm"]
-        out[tag + "_K"] = tril_pack(K)
-        out[tag + "_wt"] = r["wt"][:, : int(r["lens"].max())]
-        out["lens"] = r["lens"]
-        out["n_pos"] = np.array(npos)
-        print("quirks", (t, L, k, d, M, H, g), "N", n, "npos", npos)
-    np.savez_compressed(os.path.join(HERE, "quirks_expected.npz"), **out)
-
-    # (iv)/(v) synthetic configs (inputs are regenerated from gkmqc_amd.synth, not stored)
     tmp = os.path.join(ROOT, "gpurun_out", "golden_tmp")
     os.makedirs(tmp, exist_ok=True)
-    cfgs = {
-        # name: (n_pos, n_neg, length, length_range, t, L, k, d)
-        "c1_full": (200, 200, 300, None, 2, 10, 6, 3),
-        "c2_cut192": (192, 192, 300, None, 4, 11, 7, 3),
-        "c5_cut64": (64, 64, None, (150, 600), 4, 12, 8, 4),
-    }
-    syn = {}
-    for name, (npos, nneg, ln, lr, t, L, k, d) in cfgs.items():
+    if not args.only_full:
+        # (i) mismatch weights c_m, bit patterns as hex
+        wt = {}
+        for (t, L, k, d) in WEIGHT_TUPLES:
+            if O.lib().gkmo_check_params(t, L, k, d):
+                continue
+            wt["%d,%d,%d,%d" % (t, L, k, d)] = [float(x).hex() for x in O.ref_weights(t, L, k, d)]
+        json.dump(wt, open(os.path.join(HERE, "mismatch_weights.json"), "w"), indent=0, sort_keys=True)
+
+        # (ii)+(iii) quirks FASTA: lengths, positional weights, sqnorm, int profiles, K
+        pp, pn = write_quirks()
+        out = {}
+        for idx, (t, L, k, d, M, H, g) in enumerate(QUIRK_PARAMS):
+            opt = O.make_opt(t, L, k, d, M, H, g, pp, pn, nthreads=4)
+            r = O.ref_profiles(opt)
+            n = r["n"]
+            K, npos = ref_K(opt, n)
+            tag = "q%d" % idx
+            out[tag + "_params"] = np.array([t, L, k, d, M, H, g], dtype=np.float64)
+            out[tag + "_P"] = r["P"]
+            out[tag + "_sqnorm"] = r["sqnorm"]
+            out[tag + "_K"] = tril_pack(K)
+            out[tag + "_wt"] = r["wt"][:, : int(r["lens"].max())]
+            out["lens"] = r["lens"]
+            out["n_pos"] = np.array(npos)
+            print("quirks", (t, L, k, d, M, H, g), "N", n, "npos", npos)
+        np.savez_compressed(os.path.join(HERE, "quirks_expected.npz"), **out)
+
+        # (iv)/(v) synthetic configs (inputs are regenerated from gkmqc_amd.synth, not stored)
+        cfgs = {
+            # name: (n_pos, n_neg, length, length_range, t, L, k, d)
+            "c1_full": (200, 200, 300, None, 2, 10, 6, 3),
+            "c2_cut192": (192, 192, 300, None, 4, 11, 7, 3),
+            "c5_cut64": (64, 64, None, (150, 600), 4, 12, 8, 4),
+        }
+        syn = {}
+        for name, (npos, nneg, ln, lr, t, L, k, d) in cfgs.items():
+            pf, nf = os.path.join(tmp, name + "_p.fa"), os.path.join(tmp, name + "_n.fa")
+            synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
+            opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=8)
+            K, _ = ref_K(opt, npos + nneg)
+            syn[name + "_K"] = tril_pack(K)
+            syn[name + "_cfg"] = np.array([npos, nneg, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0, t, L, k, d])
+            if name != "c1_full":
+                r = O.ref_profiles(opt)
+                syn[name + "_P"] = r["P"]
+                syn[name + "_sqnorm"] = r["sqnorm"]
+            print(name, "done")
+        np.savez_compressed(os.path.join(HERE, "synthetic_expected.npz"), **syn)
+
+    fulls = list(args.full or []) + (["c2"] if args.c2_full else [])
+    for name in fulls:
+        # (vi) a BASELINE configuration at FULL size through the reference: digest + sampled entries + row sums
+        import time
+        npos, nneg, ln, lr, t, L, k, d = FULL_CONFIGS[name]
         pf, nf = os.path.join(tmp, name + "_p.fa"), os.path.join(tmp, name + "_n.fa")
         synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
-        opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=8)
-        K, _ = ref_K(opt, npos + nneg)
-        syn[name + "_K"] = tril_pack(K)
-        syn[name + "_cfg"] = np.array([npos, nneg, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0, t, L, k, d])
-        if name != "c1_full":
-            r = O.ref_profiles(opt)
-            syn[name + "_P"] = r["P"]
-            syn[name + "_sqnorm"] = r["sqnorm"]
-        print(name, "done")
-    np.savez_compressed(os.path.join(HERE, "synthetic_expected.npz"), **syn)
-
-    if args.c2_full:
-        # (vi) full C2 through the reference: digest + sampled entries + row sums
-        import time
-        npos = nneg = 5000
-        pf, nf = os.path.join(tmp, "c2_p.fa"), os.path.join(tmp, "c2_n.fa")
-        synth.write_problem(pf, nf, npos, nneg, 300)
-        opt = O.make_opt(4, 11, 7, 3, 50, 50.0, 1.0, pf, nf, nthreads=os.cpu_count())
+        opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=os.cpu_count())
         t0 = time.time()
         K, _ = ref_K(opt, npos + nneg)
         wall = time.time() - t0
         tri = tril_pack(K)
         rng = np.random.default_rng(7)
         sel = rng.choice(tri.size, 4000, replace=False)
-        np.savez_compressed(os.path.join(HERE, "c2_full_digest.npz"),
+        np.savez_compressed(os.path.join(HERE, name + "_full_digest.npz"),
                             sha256=np.frombuffer(hashlib.sha256(tri.tobytes()).digest(), dtype=np.uint8),
                             sample_idx=sel, sample_val=tri[sel],
                             row_sums=np.tril(K, -1).sum(axis=1), total=np.array(tri.sum()),
-                            ref_wall_s=np.array(wall), ref_threads=np.array(os.cpu_count()))
-        print("c2 full: reference wall %.1f s on %d threads" % (wall, os.cpu_count()))
+                            ref_wall_s=np.array(wall), ref_threads=np.array(os.cpu_count()),
+                            cfg=np.array([npos, nneg, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0, t, L, k, d]))
+        print("%s full: reference wall %.1f s on %d threads" % (name, wall, os.cpu_count()), flush=True)
+        del K, tri
 
 
 if __name__ == "__main__":

@@ -155,22 +155,32 @@ def test_boundary_end_to_end(dev):
         assert helpers.max_rel_err(helpers.tril_pack(kmat[:n, :n]), c["K"]) < tol
 
 
-def test_c2_full_size_against_reference_digest(dev):
-    """BASELINE config 2 at full size (5000+5000 x 300 bp, L=11 k=7 d=3, wgkm): sampled entries,
-    row sums and total of the reference's matrix (computed once by tests/golden/make_golden.py)."""
-    path = os.path.join(helpers.GOLDEN, "c2_full_digest.npz")
+FULL_CONFIGS = {"c2": (5000, 5000, 300, None, 4, 11, 7, 3),       # BASELINE.json configs[1] (the headline)
+                "c3": (10000, 10000, 300, None, 4, 11, 7, 3),     # configs[2]
+                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4)}  # configs[4]
+
+
+@pytest.mark.parametrize("name", sorted(FULL_CONFIGS))
+def test_full_size_against_reference_digest(dev, name):
+    """BASELINE configurations at FULL size: SHA-256 of the lower triangle, sampled entries, row
+    sums and total of the reference's own matrix (computed once in the build container by
+    tests/golden/make_golden.py --full; the reference needs minutes to an hour per matrix)."""
+    path = os.path.join(helpers.GOLDEN, name + "_full_digest.npz")
     if not os.path.exists(path):
         pytest.skip("digest fixture missing")
     z = np.load(path)
-    seqs = helpers.synth_codes(5000, 5000, 300)
-    res = dev.gram_matrix(seqs, 4, 11, 7, 3)
+    npos, nneg, ln, lr, t, L, k, d = FULL_CONFIGS[name]
+    seqs = helpers.synth_codes(npos, nneg, ln or 300, lr)
+    res = dev.gram_matrix(seqs, t, L, k, d)
     K = res["K"].cpu().numpy()
+    del res["K"]
     tri = helpers.tril_pack(K)
     assert helpers.max_rel_err(tri[z["sample_idx"]], z["sample_val"]) < K_TOL
     assert helpers.max_rel_err(np.tril(K, -1).sum(axis=1)[1:], z["row_sums"][1:]) < 1e-10
     assert abs(tri.sum() - float(z["total"])) < 1e-9 * abs(float(z["total"]))
     same = hashlib.sha256(tri.tobytes()).digest() == z["sha256"].tobytes()
-    print("C2 full: %s, %.1f ms device, bit-identical to the reference: %s" % (res["kernel"], res["ms"], same))
+    print("%s full: %s, %.1f ms device, bit-identical to the reference: %s" % (name, res["kernel"], res["ms"], same))
+    assert same, "K differs from the reference in the last bits (still within %g)" % K_TOL
 
 
 def _oracle_profiles(seqs, t, L, k, d, M=50, H=50.0):
