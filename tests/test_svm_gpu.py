@@ -79,6 +79,16 @@ def test_solver_is_bit_identical_to_sklearn(built, n, dim, C, tol, dup):
     _compare_with_sklearn(K, n // 2, trains, tests, C, tol)
 
 
+@pytest.mark.parametrize("shape", ["256x8", "512x8", "1024x4", "1024x8", "512x16", "1024x16"])
+def test_every_launch_shape(built, monkeypatch, shape):
+    """The launcher picks threads x samples-per-thread from the fold size; force each instantiation
+    (incl. the register-table variant used above 8192 samples) on the same problem."""
+    monkeypatch.setenv("GKM_SVM_SHAPE", shape)
+    K = _rbf_matrix(700, 8, seed=11, dup=10)
+    trains, tests = _folds(700, 350, 2, seed=2)
+    _compare_with_sklearn(K, 350, trains, tests, 1.0, 1e-3)
+
+
 def test_unbalanced_and_tiny_folds(built):
     K = _rbf_matrix(90, 3, seed=5)
     trains, tests = _folds(90, 12, 4, seed=3)
