@@ -312,7 +312,8 @@ constexpr int BS_TRIP = 128;  /* records resolved per trip (2 per lane) */
 #define GKM_BS_DU 3 /* A/B on config 2: 2 -> 114.9 ms, 3 -> 114.8, 5 -> 118.0, 10 -> 117.9 */
 #endif
 #ifndef GKM_BS_WAVES
-#define GKM_BS_WAVES 1
+#define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
+                          config 2 with the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 */
 #endif
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 
@@ -325,7 +326,7 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * control flow besides the push.
  */
 template <int W, int L, int D, bool PACKED, int VARIANT = 0>
-__global__ __launch_bounds__(64, GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
      * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
