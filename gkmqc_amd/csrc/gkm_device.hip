@@ -478,7 +478,8 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
             const sb_ptr sbl = sbh + A.xw;
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
                 /* (copying the words to VGPRs once instead of using them as SGPR operands was measured
-                 * slower: 119-129 ms against 111.6 ms on config 2) */
+                 * slower: 119-129 ms against 111.6 ms on config 2; requesting the next block's words one
+                 * block ahead changes nothing: 92.3 against 92.4 ms) */
                 /* the strand's window-validity plane (third SB plane) is not streamed: wrapped
                  * windows are rejected when a hit is resolved (gkm_bitslice.h window_hits) */
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
