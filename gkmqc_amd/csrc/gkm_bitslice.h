@@ -197,6 +197,7 @@ GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
 }
 
 constexpr int TT_A_AND_BXC = 0x60; /* a & (b ^ c) */
+constexpr int TT_BXC_AND_AXC = 0x42; /* (b ^ c) & (a ^ c) */
 
 /* sum of N one-bit planes as an exact bit-sliced count (carry-save adder tree: 2 ops per
  * full adder).  Used once per shift for the first window. */
@@ -240,8 +241,8 @@ struct PlaneSum {
  *
  * Window counts: the first window (w = 0) is summed with an adder tree; every further window
  * differs from its left neighbour by one base entering and one leaving, so the exact
- * bit-sliced count is stepped by an up/down counter, 2 ops per count plane:
- *     d = Zin ^ Zout;  t_0 = d;  b_i ^= t_i;  t_{i+1} = t_i & (b_i_old ^ Zout)
+ * bit-sliced count is stepped by an up/down counter, 2 ops per count plane (1 for the last):
+ *     t_0 = Zin ^ Zout;  b_i ^= t_i;  t_{i+1} = t_i & (b_i_old ^ Zout)
  * (carry when counting up through a 1, borrow when counting down through a 0).
  */
 template <int W, int L, int D>
@@ -262,9 +263,13 @@ GKM_HD void window_hits(const uint32_t *Ahi, const uint32_t *Alo, const uint32_t
     for (int w = 0; w < W; w++) {
         if (w > 0) {
             const uint32_t zout = Z[w - 1], zin = Z[w + L - 1];
-            uint32_t t = zin ^ zout;
+            /* plane 0 straight from (b_0, Zin, Zout): b_0 ^ Zin ^ Zout and the carry/borrow
+             * (Zin ^ Zout) & (b_0 ^ Zout), one lop3 each -- no separate Zin ^ Zout */
+            const uint32_t old0 = cnt.b[0];
+            cnt.b[0] = lop3<TT_XOR3>(old0, zin, zout);
+            uint32_t t = lop3<TT_BXC_AND_AXC>(old0, zin, zout);
 #pragma unroll
-            for (int i = 0; i < P; i++) {
+            for (int i = 1; i < P; i++) {
                 const uint32_t old = cnt.b[i];
                 cnt.b[i] = old ^ t;
                 if (i + 1 < P) t = lop3<TT_A_AND_BXC>(t, old, zout);
