@@ -306,8 +306,14 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
 }
 
 constexpr int BS_GRP = 5;     /* hit words per list record: the lanes are compacted once per BS_GRP words */
-constexpr int BS_CAP = 192;   /* records the wave-wide hit list (a ring) holds; multiple of 64: merged LDS stores */
-constexpr int BS_TRIP = 128;  /* records resolved per trip (2 per lane) */
+#ifndef GKM_BS_TRIP
+#define GKM_BS_TRIP 64 /* config 2: 64 -> 87.2 ms (ring of 128: index wrap is one AND), 128 -> 89.1, 192 -> 97.3 */
+#endif
+constexpr int BS_TRIP = GKM_BS_TRIP; /* records resolved per trip (BS_TRIP / 64 per lane) */
+constexpr int BS_TK = BS_TRIP / 64;
+/* records the wave-wide hit list (a ring) holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
+constexpr int BS_CAP = BS_TRIP + 64;
+constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 #ifndef GKM_BS_DU
 #define GKM_BS_DU 3 /* A/B on config 2: 2 -> 114.9 ms, 3 -> 114.8, 5 -> 118.0, 10 -> 117.9 */
 #endif
@@ -357,7 +363,9 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
      * every group (at most 64 new records), a trip pops BS_TRIP records before it appends at most as
      * many again: the ring never holds more than BS_TRIP + 63 records. */
     static_assert(BS_CAP >= BS_TRIP + 64 && BS_CAP % 64 == 0, "hit list too small");
-    auto ring = [](uint32_t x) { return min(x, x - (uint32_t)BS_CAP); }; /* x mod BS_CAP for x < 2 BS_CAP */
+    auto ring = [](uint32_t x) { /* x mod BS_CAP for x < 2 BS_CAP */
+        return BS_CAP_POW2 ? (x & (uint32_t)(BS_CAP - 1)) : min(x, x - (uint32_t)BS_CAP);
+    };
     static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
@@ -425,9 +433,9 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
             while (s_n >= BS_TRIP || (final && s_n > 0)) {
                 const int c = min(s_n, BS_TRIP);
-                uint32_t h[2][BS_GRP], meta[2], left[2];
+                uint32_t h[BS_TK][BS_GRP], meta[BS_TK], left[BS_TK];
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < BS_TK; k++) {
                     const int i = k * 64 + lane;
                     const uint32_t at = ring((uint32_t)(s_hd + i));
 #pragma unroll
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
                 s_hd = (int)ring((uint32_t)(s_hd + c));
                 s_n -= c;
 #pragma unroll
-                for (int k = 0; k < 2; k++) {
+                for (int k = 0; k < BS_TK; k++) {
                     const unsigned long long more = __ballot(left[k] != 0u);
                     if (more) {
                         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
@@ -513,7 +521,9 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
                             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             if (any != 0u) {
-                                char *const at = (char *)s_list + (ring((uint32_t)rank + ring((uint32_t)(s_hd + s_n))) << 2);
+                                char *const at = (char *)s_list + (BS_CAP_POW2
+                                    ? ((((uint32_t)rank + (uint32_t)(s_hd + s_n)) << 2) & (uint32_t)(BS_CAP * 4 - 1))
+                                    : (ring((uint32_t)rank + ring((uint32_t)(s_hd + s_n))) << 2));
 #pragma unroll
                                 for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
                                 *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;
