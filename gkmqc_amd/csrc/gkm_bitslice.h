@@ -199,31 +199,51 @@ GKM_HD uint32_t cnt_exceeds(const Cnt<NB, MX> &v)
 constexpr int TT_A_AND_BXC = 0x60; /* a & (b ^ c) */
 constexpr int TT_BXC_AND_AXC = 0x42; /* (b ^ c) & (a ^ c) */
 
-/* sum of N one-bit planes as an exact bit-sliced count (carry-save adder tree: 2 ops per
- * full adder).  Used once per shift for the first window. */
+/* Sum of N one-bit planes as an exact bit-sliced count, used once per shift for the first
+ * window.  Column compression: the N planes of weight 1 are folded three at a time by full
+ * adders (x ^ y ^ z stays in the column, maj(x, y, z) moves to the next), a half adder takes a
+ * leftover pair; the N/2 carries are the next column.  A full adder takes one plane off the
+ * total, so this is the minimum number of them: L = 11 -> 7 full adders + 1 half adder = 16
+ * ops (the balanced tree of two-operand additions it replaces took 22). */
+template <int N>
+struct ColumnSum {
+    static constexpr int NC = N / 2; /* carries out of a column of N planes */
+    static GKM_HD uint32_t run(const uint32_t *x, uint32_t *carry)
+    {
+        uint32_t s = x[0];
+        int nc = 0;
+#pragma unroll
+        for (int i = 1; i + 1 < N; i += 2) {
+            carry[nc++] = lop3<TT_MAJ>(s, x[i], x[i + 1]);
+            s = lop3<TT_XOR3>(s, x[i], x[i + 1]);
+        }
+        if constexpr (N % 2 == 0) {
+            carry[nc++] = s & x[N - 1];
+            s ^= x[N - 1];
+        }
+        return s;
+    }
+};
+
+template <int I, int NB, int MX, int N>
+GKM_HD void plane_sum_columns(const uint32_t *x, Cnt<NB, MX> &r)
+{
+    if constexpr (N >= 1 && I < Cnt<NB, MX>::P) {
+        uint32_t carry[ColumnSum<N>::NC > 0 ? ColumnSum<N>::NC : 1];
+        r.b[I] = ColumnSum<N>::run(x, carry);
+        plane_sum_columns<I + 1, NB, MX, ColumnSum<N>::NC>(carry, r);
+    }
+}
+
 template <int NB, int N>
 struct PlaneSum {
+    static_assert(bitlen(N) <= NB, "PlaneSum: the count must fit its planes");
     static GKM_HD Cnt<NB, N> run(const uint32_t *z)
     {
-        if constexpr (N == 1) {
-            Cnt<NB, 1> r;
-            r.b[0] = z[0];
-            r.ovf = 0u;
-            return r;
-        } else if constexpr (N == 2) {
-            Cnt<NB, 1> x, y;
-            x.b[0] = z[0]; x.ovf = 0u;
-            y.b[0] = z[1]; y.ovf = 0u;
-            return cnt_add<false>(x, y);
-        } else if constexpr (N == 3) {
-            Cnt<NB, 1> x, y;
-            x.b[0] = z[0]; x.ovf = 0u;
-            y.b[0] = z[1]; y.ovf = 0u;
-            return cnt_add<true>(x, y, z[2]);
-        } else {
-            constexpr int H = ((N - 1) / 2);          /* two halves + one carry-in plane */
-            return cnt_add<true>(PlaneSum<NB, H>::run(z), PlaneSum<NB, N - 1 - H>::run(z + H), z[N - 1]);
-        }
+        Cnt<NB, N> r;
+        r.ovf = 0u;
+        plane_sum_columns<0, NB, N, N>(z, r);
+        return r;
     }
 };
 
