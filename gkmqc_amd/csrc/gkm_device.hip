@@ -137,7 +137,8 @@ struct gkmhip_ctx {
     int wd_len = 0;
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
-    DevBuf<uint32_t> lmf, lmr, sb;
+    DevBuf<uint32_t> lmf, sb; /* lmf: forward l-mer table, then the reverse-strand table */
+    uint32_t lm_stride = 0;
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch */
@@ -187,7 +188,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
-    ctx->len.release(); ctx->lmf.release(); ctx->lmr.release(); ctx->sb.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->sb.release();
     ctx->rows.release(); ctx->piece_desc.release(); ctx->tile_row.release(); ctx->tile_out.release();
     ctx->tile_nrows.release(); ctx->tile_cbeg.release(); ctx->tile_cend.release(); ctx->rowplanes.release();
     ctx->lane_mask.release();
@@ -279,6 +280,7 @@ struct BsArgs {
     const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
     const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
     const uint32_t *lmf, *lmr;  /* l-mer table entries (l-mer | weight << 24) per strand */
+    uint32_t lm_stride;         /* lmr == lmf + lm_stride */
     const int64_t *lmoff;
     const uint32_t *sb;
     int xw;
@@ -404,8 +406,8 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
         const int T = A.len[j];
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
-        const uint32_t *colf = A.lmf + A.lmoff[j], *colr = A.lmr + A.lmoff[j];
-        auto col_lmer = [&](int strand, int q) { return strand ? colr[q] : colf[q]; };
+        const uint32_t *colf = A.lmf + A.lmoff[j];
+        auto col_lmer = [&](int strand, int q) { return colf[(uint32_t)q + (strand ? A.lm_stride : 0u)]; };
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
@@ -438,9 +440,15 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
                 for (int k = 0; k < BS_TK; k++) {
                     const int i = k * 64 + lane;
                     const uint32_t at = ring((uint32_t)(s_hd + i));
+                    /* (every ring slot is readable: the lanes past the end of a short, final trip
+                     * are cleared afterwards instead of being masked out of the loads) */
 #pragma unroll
-                    for (int g = 0; g < BS_GRP; g++) h[k][g] = (i < c) ? s_list[g * BS_CAP + at] : 0u;
+                    for (int g = 0; g < BS_GRP; g++) h[k][g] = s_list[g * BS_CAP + at];
                     meta[k] = s_meta[at];
+                    if (c < BS_TRIP) { /* wave-uniform */
+#pragma unroll
+                        for (int g = 0; g < BS_GRP; g++) h[k][g] = (i < c) ? h[k][g] : 0u;
+                    }
                     /* first non-empty word of the record (scanned from the last word down) */
                     uint32_t hw = h[k][BS_GRP - 1], sel = BS_GRP - 1;
 #pragma unroll
@@ -705,9 +713,13 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
 {
     if (ctx->have_lmers) return 0;
     const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
-    if (ctx->lmf.ensure(total_lm) || ctx->lmr.ensure(total_lm)) return 4;
+    /* one buffer: the reverse-strand table sits lm_stride entries after the forward one, so the hit
+     * path selects the strand with an index offset instead of a pointer select */
+    if (total_lm >= (size_t)1 << 31) return set_err_msg("l-mer tables exceed 2^31 entries", 4);
+    if (ctx->lmf.ensure(2 * total_lm)) return 4;
+    ctx->lm_stride = (uint32_t)total_lm;
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
-                       ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmr.p);
+                       ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
     HIPCHK(hipGetLastError());
     ctx->have_lmers = true;
     return 0;
@@ -845,7 +857,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.rowplanes = ctx->rowplanes.p; A.lane_mask = ctx->lane_mask.p; A.lane_piece = ctx->lane_piece.p;
         A.tile_row = ctx->tile_row.p; A.tile_out = ctx->tile_out.p; A.tile_nrows = ctx->tile_nrows.p;
         A.tile_cbeg = ctx->tile_cbeg.p; A.tile_cend = ctx->tile_cend.p;
-        A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p; A.lmoff = ctx->lmoff.p;
+        A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride; A.lm_stride = ctx->lm_stride; A.lmoff = ctx->lmoff.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
@@ -865,7 +877,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
         DirectArgs A;
         A.rows = ctx->rows.p; A.nrows = nrows;
-        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmr.p;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.cj = 16; A.L = L; A.d = d; A.mode = mode; A.n = n;
