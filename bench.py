@@ -288,7 +288,7 @@ def main():
                     "achieved = ALGORITHMIC ops: 6 int32 ops per l-mer comparison (SURVEY op model) x "
                     "comparisons_per_launch (2 n_a n_j per pair, this rank's pairs) / kernel_ms (HIP events on the "
                     "launch stream). peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz. The bit-sliced kernel EXECUTES "
-                    "about 0.64 VALU instructions per comparison instead of 6, which is why frac exceeds 1: see DESIGN.md for "
+                    "about 0.56 VALU instructions per comparison instead of 6, which is why frac exceeds 1: see DESIGN.md for "
                     "the executed-instruction utilisation from rocprofv3 (profiles/). HBM traffic is incidental.",
         }
         if world == 1 and not args.no_cpu_baseline:
