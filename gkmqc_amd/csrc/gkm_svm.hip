@@ -425,7 +425,12 @@ struct DecProb {
 
 /* one thread per test sample; the sum runs over the training samples in LIBSVM's order.  K is
  * bit-symmetric (include/gkm_svm.h), so K(test_t, train_k) is read as K[train_k][test_t]: the
- * threads of a wave then read neighbouring addresses of one matrix row. */
+ * threads of a wave then read neighbouring addresses of one matrix row.  The loads of DEC_U
+ * training samples are in flight together (the index -> matrix row chain would otherwise cost one
+ * memory round trip per sample: the call took 5.6 ms instead of 3.5 ms for 5 folds of the headline
+ * matrix, host overhead included); the
+ * additions stay sequential, in LIBSVM's order. */
+constexpr int DEC_U = 16;
 __global__ void k_decision(const double *__restrict__ K, int64_t ld, const DecProb *probs)
 {
     const DecProb p = probs[blockIdx.y];
@@ -433,9 +438,17 @@ __global__ void k_decision(const double *__restrict__ K, int64_t ld, const DecPr
     if (t >= p.ntest) return;
     const int col = p.test[t];
     double sum = 0;
-    for (int k = 0; k < p.l; k++) {
-        const double a = p.alpha[k]; /* wave-uniform */
-        if (a > 0) sum += (k < p.n0 ? a : -a) * K[(int64_t)p.idx[k] * ld + col];
+    for (int k0 = 0; k0 < p.l; k0 += DEC_U) {
+        double a[DEC_U], kv[DEC_U];
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++) {
+            const int k = min(k0 + u, p.l - 1);
+            a[u] = k0 + u < p.l ? p.alpha[k] : 0.0; /* wave-uniform */
+            kv[u] = K[(int64_t)p.idx[k] * ld + col];
+        }
+#pragma unroll
+        for (int u = 0; u < DEC_U; u++)
+            if (a[u] > 0) sum += (k0 + u < p.n0 ? a[u] : -a[u]) * kv[u];
     }
     p.dec[t] = sum - *p.rho;
 }

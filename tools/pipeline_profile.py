@@ -53,6 +53,21 @@ def main():
         names = ["read_problem", "ctx+set_sequences", "alloc", "gram_rows", "normalize", "maximum(K,K.T)", "close", "cv"]
         print("rep %d: " % rep + "  ".join("%s %.1f ms" % (nm, (t[i + 1] - t[i]) * 1e3) for i, nm in enumerate(names))
               + "  total %.1f ms" % ((t[-1] - t[0]) * 1e3))
+        # the cross-validation in pieces
+        from sklearn.metrics import roc_auc_score
+        from sklearn.model_selection import StratifiedKFold
+        y = np.concatenate((np.repeat(1, n_pos), np.repeat(0, n - n_pos)))
+        c0 = time.perf_counter()
+        folds = list(StratifiedKFold(n_splits=5, shuffle=True, random_state=7).split(np.zeros(n), y))
+        c1 = time.perf_counter()
+        sol, h = svmcv.train_folds(K, [tr for tr, _ in folds], y, 1.0, 1e-3)
+        c2 = time.perf_counter()
+        sc = svmcv.decision_values(K, h, [te for _, te in folds])
+        c3 = time.perf_counter()
+        aucs = [roc_auc_score(y[te], s_) for (_, te), s_ in zip(folds, sc)]
+        c4 = time.perf_counter()
+        print("        cv pieces: folds %.1f ms  train %.1f ms (%d..%d iterations)  decision %.1f ms  auc %.1f ms" %
+              ((c1 - c0) * 1e3, (c2 - c1) * 1e3, int(sol.iters.min()), int(sol.iters.max()), (c3 - c2) * 1e3, (c4 - c3) * 1e3))
         t0 = time.perf_counter()
         gkmsvm.main(["-p", pos, "-n", neg, "-w", os.path.join(tmp, "out"), "-s", "7", "-v", "0", "-t", "4", "-L", "11",
                      "-k", "7", "-d", "3"])
