@@ -142,14 +142,24 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
         for train, test in folds.split(seqids, y):
             trains.append(train)
             tests.append(test)
-    logging.info("cross-validation on the GPU: %d folds", len(trains))
-    sol, handles = train_folds(K, trains, y, regularization, precision)
-    scores = decision_values(K, handles, tests)
-    aucs = []
-    for f, (test, score) in enumerate(zip(tests, scores)):
+    # With a fixed seed the reference builds every repeat from the same random_state
+    # (scripts/gkmsvm.py:148), i.e. the same folds again: solve each distinct fold once.
+    first, which = {}, []
+    for f, train in enumerate(trains):
+        which.append(first.setdefault(train.tobytes(), len(first)))
+    uniq = sorted(set(which))
+    u_of = {w: [f for f in range(len(trains)) if which[f] == w][0] for w in uniq}
+    u_trains = [trains[u_of[w]] for w in uniq]
+    u_tests = [tests[u_of[w]] for w in uniq]
+    logging.info("cross-validation on the GPU: %d folds (%d distinct)", len(trains), len(uniq))
+    sol, handles = train_folds(K, u_trains, y, regularization, precision)
+    scores = decision_values(K, handles, u_tests)
+    u_auc = []
+    for f, (test, score) in enumerate(zip(u_tests, scores)):
         auc = roc_auc_score(y[test], score)
-        nu = np.sum(sol.alpha[f]) / len(trains[f])
+        nu = np.sum(sol.alpha[f]) / len(u_trains[f])
         logging.info("SVC training and validation; nu = %.3f, AUC = %.3f, %d iterations", nu, auc, abs(int(sol.iters[f])))
-        aucs.append(auc)
+        u_auc.append(auc)
+    aucs = [u_auc[w] for w in which]
     logging.info("done cross-validation.")
     return (np.mean(aucs), np.std(aucs))
