@@ -407,7 +407,11 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
         const uint32_t *colf = A.lmf + A.lmoff[j];
-        auto col_lmer = [&](int strand, int q) { return colf[(uint32_t)q + (strand ? A.lm_stride : 0u)]; };
+        /* (32-bit byte offsets from a wave-uniform base: global_load with an SGPR base instead of a
+         * 64-bit address computed per lane; the tables stay below 4 GB, ensure_lmers checks) */
+        auto col_lmer = [&](int strand, int q) {
+            return *(const uint32_t *)((const char *)colf + (((uint32_t)q + (strand ? A.lm_stride : 0u)) << 2));
+        };
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
@@ -421,7 +425,7 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
             const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], rec_bit(rec)) : 0;
             const uint32_t slot = lpiece[(r * NP + k) * 2];
             const uint32_t base = lpiece[(r * NP + k) * 2 + 1]; /* lmoff[row] + p0 - b0*W (mod 2^32) */
-            auto row_lmer = [&](int i0) { return A.lmf[base + (uint32_t)i0]; };
+            auto row_lmer = [&](int i0) { return *(const uint32_t *)((const char *)A.lmf + ((base + (uint32_t)i0) << 2)); };
             const HitValue hv = resolve_hit<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
                                                rcpT, nB, row_lmer, col_lmer);
             if (hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
@@ -715,7 +719,7 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
     const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
     /* one buffer: the reverse-strand table sits lm_stride entries after the forward one, so the hit
      * path selects the strand with an index offset instead of a pointer select */
-    if (total_lm >= (size_t)1 << 31) return set_err_msg("l-mer tables exceed 2^31 entries", 4);
+    if (total_lm >= (size_t)1 << 29) return set_err_msg("l-mer tables exceed 2^29 entries per strand", 4);
     if (ctx->lmf.ensure(2 * total_lm)) return 4;
     ctx->lm_stride = (uint32_t)total_lm;
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
