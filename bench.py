@@ -123,6 +123,13 @@ def main():
     ap.add_argument("--check", action="store_true", help="compare the assembled matrix with a 1-GPU run (debug)")
     args = ap.parse_args()
 
+    # stdout carries exactly one JSON line.  Libraries write there too (RCCL prints its version
+    # banner on file descriptor 1 when stderr is not a file), so descriptor 1 is pointed at stderr
+    # for the duration of the run and the line goes to a private copy of the real stdout.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from gkmqc_amd import device, sharding
@@ -136,7 +143,11 @@ def main():
     dist_on = world > 1 or os.environ.get("GKM_BENCH_FORCE_DIST") == "1"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:   # only the one-rank rehearsal comes without one
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
@@ -293,7 +304,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, args.L, args.k, args.d, args.kernel_type)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=real_stdout, flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()

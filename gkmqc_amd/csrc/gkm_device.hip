@@ -866,7 +866,11 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
-        A.cj = 4; /* small work items: better tail balance (sweep: 4 -> 192 ms, 16 -> 197, 64 -> 221) */
+        /* one column sequence per work item: a wave of the full-size problem lives ~0.6 ms (2.3 ms with four
+         * columns), which is what the drain at the end of every launch costs -- nothing for one big launch
+         * (config 2: 84.3 vs 85.4 ms) but ~1 ms per launch for the boundary's 13 row blocks (106 -> 96 ms per
+         * call) and for the chunks of the multi-GPU path */
+        A.cj = 1;
         const char *e = getenv("GKM_CJ");
         if (e && atoi(e) > 0) A.cj = atoi(e);
         const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
