@@ -186,25 +186,38 @@ def main():
         gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64, device=dev)
         slot_of_row = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks)).to(dev)
 
-    def compute(c, out_ptr, local):
+    def compute(c, out_ptr, local, on=None):
         if len(parts[c]):
-            ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream)
+            ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream if on is None else on)
+
+    # Two side streams, chunks alternate between them: the kernel of chunk c+1 fills the CUs that the
+    # drain of chunk c leaves idle, and its all-gather overlaps as before.
+    side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if dist_on else None
 
     def step():
         if not dist_on:
             compute(0, full.data_ptr(), False)
         else:
+            main = torch.cuda.current_stream()
             pending = []
             for c in range(chunks):
-                compute(c, slab[c].data_ptr(), True)
-                if backend == "nccl":   # RCCL over xGMI, asynchronous: overlaps the next chunk's kernel
-                    pending.append(dist.all_gather_into_tensor(gathered[c], slab[c], async_op=True))
-                else:                   # rehearsal through host memory
-                    host = torch.empty(gathered[c].shape, dtype=gathered.dtype)
-                    dist.all_gather_into_tensor(host, slab[c].cpu())
-                    gathered[c].copy_(host)
+                st = side[c & 1]
+                if c < 2:
+                    st.wait_stream(main)        # the previous step has finished reading slab / gathered
+                ctx.set_scratch_slot(c & 1)     # chunks c and c+2 share a slot and a stream
+                with torch.cuda.stream(st):
+                    compute(c, slab[c].data_ptr(), True, st.cuda_stream)
+                    if backend == "nccl":   # RCCL over xGMI, asynchronous: overlaps the next chunk's kernel
+                        pending.append(dist.all_gather_into_tensor(gathered[c], slab[c], async_op=True))
+                    else:                   # rehearsal through host memory
+                        host = torch.empty(gathered[c].shape, dtype=gathered.dtype)
+                        dist.all_gather_into_tensor(host, slab[c].cpu())
+                        gathered[c].copy_(host)
+            ctx.set_scratch_slot(0)
             for w in pending:
                 w.wait()
+            main.wait_stream(side[0])
+            main.wait_stream(side[1])
             torch.index_select(gathered.view(chunks * world * pc, n), 0, slot_of_row, out=full)
         ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
 

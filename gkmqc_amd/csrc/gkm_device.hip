@@ -141,9 +141,18 @@ struct gkmhip_ctx {
     uint32_t lm_stride = 0;
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
-    /* per-call scratch */
-    DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_cbeg, tile_cend;
-    DevBuf<uint32_t> rowplanes, lane_mask, lane_piece;
+    /* per-call scratch, two sets (gkmhip_set_scratch_slot): a caller that alternates launches between
+     * two streams alternates the slot, so a launch never rewrites what the previous one still reads */
+    struct Scratch {
+        DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_cbeg, tile_cend;
+        DevBuf<uint32_t> rowplanes, lane_mask, lane_piece;
+        void release()
+        {
+            rows.release(); piece_desc.release(); tile_row.release(); tile_out.release(); tile_nrows.release();
+            tile_cbeg.release(); tile_cend.release(); rowplanes.release(); lane_mask.release(); lane_piece.release();
+        }
+    } scratch[2];
+    int sel = 0;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
@@ -189,13 +198,17 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipDeviceSynchronize();
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->sb.release();
-    ctx->rows.release(); ctx->piece_desc.release(); ctx->tile_row.release(); ctx->tile_out.release();
-    ctx->tile_nrows.release(); ctx->tile_cbeg.release(); ctx->tile_cend.release(); ctx->rowplanes.release();
-    ctx->lane_mask.release();
-    ctx->lane_piece.release(); ctx->sq.release();
+    ctx->scratch[0].release(); ctx->scratch[1].release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
+}
+
+extern "C" int gkmhip_set_scratch_slot(gkmhip_ctx *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot > 1) return set_err_msg("bad scratch slot", 2);
+    ctx->sel = slot;
+    return 0;
 }
 
 extern "C" int gkmhip_set_kernel(gkmhip_ctx *ctx, int which)
@@ -830,17 +843,17 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             lane_piece[((size_t)pc.lane * NP + k) * 2 + 1] =
                 (uint32_t)(ctx->h_lmoff[(size_t)pc.row] + pc.p0 - (int64_t)pc.b0 * W);
         }
-        if (ctx->piece_desc.ensure(desc.size()) || ctx->lane_mask.ensure(nl) || ctx->lane_piece.ensure(lane_piece.size()) ||
-            ctx->tile_row.ensure(pk.tile_row.size()) || ctx->tile_out.ensure(pk.tile_out.size()) ||
-            ctx->tile_nrows.ensure((size_t)ntiles) || ctx->tile_cbeg.ensure((size_t)ntiles) || ctx->tile_cend.ensure((size_t)ntiles) ||
-            ctx->rowplanes.ensure(nl * 3 * W))
+        if (ctx->scratch[ctx->sel].piece_desc.ensure(desc.size()) || ctx->scratch[ctx->sel].lane_mask.ensure(nl) || ctx->scratch[ctx->sel].lane_piece.ensure(lane_piece.size()) ||
+            ctx->scratch[ctx->sel].tile_row.ensure(pk.tile_row.size()) || ctx->scratch[ctx->sel].tile_out.ensure(pk.tile_out.size()) ||
+            ctx->scratch[ctx->sel].tile_nrows.ensure((size_t)ntiles) || ctx->scratch[ctx->sel].tile_cbeg.ensure((size_t)ntiles) || ctx->scratch[ctx->sel].tile_cend.ensure((size_t)ntiles) ||
+            ctx->scratch[ctx->sel].rowplanes.ensure(nl * 3 * W))
             return 4;
-        HIPCHK(hipMemcpyAsync(ctx->piece_desc.p, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->lane_mask.p, lane_mask.data(), nl * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->lane_piece.p, lane_piece.data(), lane_piece.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_row.p, pk.tile_row.data(), pk.tile_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_out.p, pk.tile_out.data(), pk.tile_out.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_nrows.p, pk.tile_nrows.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].piece_desc.p, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].lane_mask.p, lane_mask.data(), nl * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].lane_piece.p, lane_piece.data(), lane_piece.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_row.p, pk.tile_row.data(), pk.tile_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_out.p, pk.tile_out.data(), pk.tile_out.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_nrows.p, pk.tile_nrows.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
         std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
         int span = 0;
         for (int t = 0; t < ntiles; t++) {
@@ -850,17 +863,17 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
             span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
         }
-        HIPCHK(hipMemcpyAsync(ctx->tile_cbeg.p, cbeg.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->tile_cend.p, cend.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_cbeg.p, cbeg.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_cend.p, cend.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
         /* the host vectors above are pageable: the copies have completed on return */
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, ctx->piece_desc.p, W, ctx->rowplanes.p);
+                           ctx->off.p, ctx->scratch[ctx->sel].piece_desc.p, W, ctx->scratch[ctx->sel].rowplanes.p);
         HIPCHK(hipGetLastError());
 
         BsArgs A;
-        A.rowplanes = ctx->rowplanes.p; A.lane_mask = ctx->lane_mask.p; A.lane_piece = ctx->lane_piece.p;
-        A.tile_row = ctx->tile_row.p; A.tile_out = ctx->tile_out.p; A.tile_nrows = ctx->tile_nrows.p;
-        A.tile_cbeg = ctx->tile_cbeg.p; A.tile_cend = ctx->tile_cend.p;
+        A.rowplanes = ctx->scratch[ctx->sel].rowplanes.p; A.lane_mask = ctx->scratch[ctx->sel].lane_mask.p; A.lane_piece = ctx->scratch[ctx->sel].lane_piece.p;
+        A.tile_row = ctx->scratch[ctx->sel].tile_row.p; A.tile_out = ctx->scratch[ctx->sel].tile_out.p; A.tile_nrows = ctx->scratch[ctx->sel].tile_nrows.p;
+        A.tile_cbeg = ctx->scratch[ctx->sel].tile_cbeg.p; A.tile_cend = ctx->scratch[ctx->sel].tile_cend.p;
         A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride; A.lm_stride = ctx->lm_stride; A.lmoff = ctx->lmoff.p;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
@@ -881,10 +894,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         ctx->last_kernel = packed ? "k_gram_bitslice<packed>" : "k_gram_bitslice";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
-        if (ctx->rows.ensure((size_t)nrows)) return 4;
-        HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
         DirectArgs A;
-        A.rows = ctx->rows.p; A.nrows = nrows;
+        A.rows = ctx->scratch[ctx->sel].rows.p; A.nrows = nrows;
         A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
@@ -970,10 +983,10 @@ extern "C" int gkmhip_normalize_rows_full(gkmhip_ctx *ctx, const int *rows, int 
     if (!ctx || !rows || nrows <= 0 || !G || !sqnorm) return set_err_msg("gkmhip_normalize_rows_full: bad arguments", 2);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(ctx->device));
-    if (ctx->rows.ensure((size_t)nrows)) return 4;
-    HIPCHK(hipMemcpyAsync(ctx->rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
+    HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_normalize_full, dim3((unsigned)((ctx->n + 255) / 256), (unsigned)nrows), dim3(256), 0, stream, G, ld,
-                       ctx->rows.p, local_rows, ctx->n, sqnorm, ctx->rbf, ctx->gamma);
+                       ctx->scratch[ctx->sel].rows.p, local_rows, ctx->n, sqnorm, ctx->rbf, ctx->gamma);
     HIPCHK(hipGetLastError());
     return 0;
 }

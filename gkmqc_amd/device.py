@@ -95,6 +95,8 @@ def load():
     L.gkmhip_destroy.argtypes = (vp,)
     L.gkmhip_set_kernel.restype = i32
     L.gkmhip_set_kernel.argtypes = (vp, i32)
+    L.gkmhip_set_scratch_slot.restype = i32
+    L.gkmhip_set_scratch_slot.argtypes = (vp, i32)
     L.gkmhip_set_sequences.restype = i32
     L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, i32, vp)
     L.gkmhip_gram_rows.restype = i32
@@ -246,6 +248,10 @@ class GramContext:
 
     def set_kernel(self, which):
         self._chk(self.lib.gkmhip_set_kernel(self.handle, which), "gkmhip_set_kernel")
+
+    def set_scratch_slot(self, slot):
+        """Launches alternating between two streams alternate the scratch slot (include/gkm_hip.h)."""
+        self._chk(self.lib.gkmhip_set_scratch_slot(self.handle, slot), "gkmhip_set_scratch_slot")
 
     def set_sequences(self, seqs, stream=0):
         """seqs: list of uint8 arrays of base codes 0..3, or a FlatSequences."""

@@ -38,26 +38,35 @@ def gather_index(n, world_size):
     return slot_of_row
 
 
+CHUNK_GROUP = 64    # rows dealt to a chunk at a time: one 64-lane tile of the Gram kernel for fixed-length data
+
+
+def _chunk_of_position(count, chunks):
+    """Chunk of each of `count` consecutive positions of a rank's row list."""
+    return (np.arange(count) // CHUNK_GROUP) % chunks
+
+
 def chunked_layout(n, world_size, rank, chunks):
-    """Split this rank's rows into `chunks` interleaved sub-lists (row i of the rank's list goes
-    to chunk i % chunks, so every chunk carries the same mix of cheap and expensive rows).  The
-    Gram kernel runs once per chunk and each chunk's slab is all-gathered on its own, which lets
-    the collective of chunk c overlap the kernel of chunk c+1.
-    Returns (list of ascending row arrays, rows_per_chunk)."""
+    """Split this rank's rows into `chunks` sub-lists.  The rank's rows are dealt to the chunks in
+    groups of CHUNK_GROUP CONSECUTIVE rows, round robin: every chunk carries the same mix of cheap
+    and expensive rows, and the rows a tile of the kernel holds stay neighbours (a tile visits all
+    columns up to its largest row, so a tile of rows 4 apart would do 3.8 % more work on the
+    headline problem).  The Gram kernel runs once per chunk and each chunk's slab is all-gathered on
+    its own, which lets the collective of chunk c overlap the kernel of chunk c+1.
+    Returns (list of ascending row arrays, rows_per_chunk = slab height of every chunk)."""
     rows, _ = folded_rows(n, world_size, rank)
     per = slab_rows(n, world_size)
-    pc = -(-per // chunks)
-    return [rows[c::chunks] for c in range(chunks)], pc
+    which = _chunk_of_position(len(rows), chunks)
+    pc = int(np.bincount(_chunk_of_position(per, chunks), minlength=chunks).max())
+    return [rows[which == c] for c in range(chunks)], pc
 
 
 def chunked_gather_index(n, world_size, chunks):
     """slot_of_row[a] = row index of matrix row a inside the concatenation over chunks c of the
     all-gathered tensors [world_size * rows_per_chunk, n]."""
-    per = slab_rows(n, world_size)
-    pc = -(-per // chunks)
     slot_of_row = np.full(n, -1, dtype=np.int64)
     for g in range(world_size):
-        parts, _ = chunked_layout(n, world_size, g, chunks)
+        parts, pc = chunked_layout(n, world_size, g, chunks)
         for c, r in enumerate(parts):
             slot_of_row[r] = (c * world_size + g) * pc + np.arange(len(r))
     assert (slot_of_row >= 0).all()

@@ -49,6 +49,11 @@ gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, do
 void gkmhip_destroy(gkmhip_ctx *ctx);
 
 /* choose the kernel family (default AUTO: bit-sliced where supported) */
+/* Per-launch scratch (row tables of one gkmhip_gram_rows* call) exists twice.  A caller that issues
+ * consecutive launches on two different streams, so that one launch fills the CUs the previous one is
+ * draining, selects slot 0 / 1 alternately; launches that share a slot must share a stream. */
+int gkmhip_set_scratch_slot(gkmhip_ctx *ctx, int slot);
+
 int gkmhip_set_kernel(gkmhip_ctx *ctx, int which);
 
 /* Upload n sequences.  codes: base codes 0..3, concatenated; offsets[n+1] (elements).

@@ -49,7 +49,8 @@ def test_chunked_layout_properties():
                         assert (np.diff(p) > 0).all()
                         seen[p] += 1
                 assert (seen == 1).all()
-                assert slot.max() < chunks * world * (-(-sharding.slab_rows(n, world) // chunks))
+                assert slot.max() < chunks * world * pc
+                assert pc <= -(-sharding.slab_rows(n, world) // chunks) + sharding.CHUNK_GROUP, "little padding"
 
 
 def _free_port():
