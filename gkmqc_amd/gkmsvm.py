@@ -86,7 +86,12 @@ def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs):
     """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p]."""
     if not isinstance(_kmat, np.ndarray):      # torch CUDA tensor: the matrix stays in HBM
         from . import svmcv
-        return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs)
+        ncv_ = max(2, int(args_svm[4]))
+        if (n_pseqs + n_nseqs) * (ncv_ - 1) / ncv_ <= svmcv.MAX_FOLD_SAMPLES:
+            return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs)
+        logging.warning("folds of more than %d samples: cross-validation with scikit-learn on the host",
+                        svmcv.MAX_FOLD_SAMPLES)
+        _kmat = _kmat.cpu().numpy()
     from sklearn.model_selection import StratifiedKFold
     global _KMAT
     ncv, repeats, fast_estimation, random_seeds, p = args_svm[4:9]

@@ -19,6 +19,9 @@ import numpy as np
 from . import device
 
 
+MAX_FOLD_SAMPLES = 16384   # one workgroup per fold: 1024 threads x 16 samples (gkm_svm.hip)
+
+
 class SvmError(RuntimeError):
     pass
 
