@@ -320,7 +320,10 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     return x;
 }
 
-constexpr int BS_GRP = 5;     /* hit words per list record: the lanes are compacted once per BS_GRP words */
+#ifndef GKM_BS_GRP
+#define GKM_BS_GRP 5 /* config 2 / gkmQC's default L=10 k=6 d=3: 2 -> 89.8 / 118.1 ms, 5 -> 81.0 / 119.3, 10 -> 87.5 / 138.3 */
+#endif
+constexpr int BS_GRP = GKM_BS_GRP;     /* hit words per list record: the lanes are compacted once per BS_GRP words */
 #ifndef GKM_BS_TRIP
 #define GKM_BS_TRIP 64 /* config 2: 64 -> 87.2 ms (ring of 128: index wrap is one AND), 128 -> 89.1, 192 -> 97.3 */
 #endif
