@@ -775,22 +775,14 @@ static bs_kernel_t pick_bitslice(int L, int d)
         if (vi == 16) return k_gram_bitslice<W, 11, 3, PACKED, 16>;
         if (vi == 32) return k_gram_bitslice<W, 11, 3, PACKED, 32>;
     }
-    GKM_BS(10, 3)
-    GKM_BS(11, 3)
-    GKM_BS(12, 4)
-    GKM_BS(8, 4)
-    GKM_BS(9, 4)
-    GKM_BS(4, 2)
+    /* every (L, d) the parameter check admits (3 <= L <= 12, d <= min(4, L - 1)), plus (12, 6) for the
+     * device layer's own tests */
+#define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
+    GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
+    GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
+    GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
     GKM_BS(12, 6)
-    GKM_BS(10, 4)
-    GKM_BS(11, 4)
-    GKM_BS(12, 3)
-    GKM_BS(9, 3)
-    GKM_BS(8, 3)
-    GKM_BS(8, 2)
-    GKM_BS(7, 3)
-    GKM_BS(6, 3)
-    GKM_BS(6, 2)
+#undef GKM_BS_L
 #undef GKM_BS
     return nullptr;
 }

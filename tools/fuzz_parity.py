@@ -13,8 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-BITSLICED = [(10, 3), (11, 3), (12, 4), (8, 4), (9, 4), (4, 2), (10, 4), (11, 4), (12, 3), (9, 3), (8, 3), (8, 2), (7, 3),
-             (6, 3), (6, 2)]
+BITSLICED = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)]   # all have a bit-sliced kernel
 
 
 def main():
