@@ -84,64 +84,88 @@ __device__ __forceinline__ double dpp_d(double x)
 }
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;
 
-template <bool MINIMISE, int CTRL>
-__device__ __forceinline__ void select_step(double &v, int &k, int &tag)
-{
-    const double ov = dpp_d<CTRL>(v);
-    const int ok = dpp_i<CTRL>(k), ot = dpp_i<CTRL>(tag);
-    if (better<MINIMISE>(ov, ok, v, k)) { v = ov; k = ok; tag = ot; }
-}
-
-/* best (v, k) of each row of 16 lanes, in all its lanes; `tag` travels with the winner */
+/* v_max_f64 / v_min_f64 without the canonicalisation hipcc wraps around fmax()/fmin() (the values
+ * compared here are never signalling NaNs) */
 template <bool MINIMISE>
-__device__ __forceinline__ void row_select(double &v, int &k, int &tag)
+__device__ __forceinline__ double extreme2(double a, double b)
 {
-    select_step<MINIMISE, DPP_XOR1>(v, k, tag);
-    select_step<MINIMISE, DPP_XOR2>(v, k, tag);
-    select_step<MINIMISE, DPP_HALF_MIRROR>(v, k, tag);
-    select_step<MINIMISE, DPP_MIRROR>(v, k, tag);
+    double r;
+    if (MINIMISE) asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    else asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
-/* best (v, k) of the wave, in all its lanes */
+/* extreme of each row of 16 lanes, in all its lanes */
 template <bool MINIMISE>
-__device__ __forceinline__ void wave_select(double &v, int &k)
+__device__ __forceinline__ double row_extreme(double v)
 {
-    int tag = 0;
-    row_select<MINIMISE>(v, k, tag);
-    double bv = v;
-    int bk = k;
-#pragma unroll
-    for (int row = 0; row < 4; row++) {
-        const int ok = __builtin_amdgcn_readlane(k, row * 16);
-        const double ov = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), row * 16),
-                                           __builtin_amdgcn_readlane(__double2loint(v), row * 16));
-        if (row == 0 || better<MINIMISE>(ov, ok, bv, bk)) { bv = ov; bk = ok; }
-    }
-    v = bv;
-    k = bk;
+    v = extreme2<MINIMISE>(v, dpp_d<DPP_XOR1>(v));
+    v = extreme2<MINIMISE>(v, dpp_d<DPP_XOR2>(v));
+    v = extreme2<MINIMISE>(v, dpp_d<DPP_HALF_MIRROR>(v));
+    v = extreme2<MINIMISE>(v, dpp_d<DPP_MIRROR>(v));
+    return v;
 }
-
-__device__ __forceinline__ double row_max(double v)
+__device__ __forceinline__ int row_imax(int v)
 {
-    v = fmax(v, dpp_d<DPP_XOR1>(v));
-    v = fmax(v, dpp_d<DPP_XOR2>(v));
-    v = fmax(v, dpp_d<DPP_HALF_MIRROR>(v));
-    v = fmax(v, dpp_d<DPP_MIRROR>(v));
+    v = max(v, dpp_i<DPP_XOR1>(v));
+    v = max(v, dpp_i<DPP_XOR2>(v));
+    v = max(v, dpp_i<DPP_HALF_MIRROR>(v));
+    v = max(v, dpp_i<DPP_MIRROR>(v));
     return v;
 }
 
-__device__ __forceinline__ double wave_max(double v)
+/* extreme of the wave, in all its lanes: rows by DPP, the four rows through SGPRs */
+template <bool MINIMISE>
+__device__ __forceinline__ double wave_extreme(double v)
 {
-    v = row_max(v);
-    double m = v;
+    v = row_extreme<MINIMISE>(v);
+    double m = 0.0;
 #pragma unroll
     for (int row = 0; row < 4; row++) {
         const double o = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), row * 16),
                                           __builtin_amdgcn_readlane(__double2loint(v), row * 16));
-        m = row == 0 ? o : fmax(m, o);
+        m = row == 0 ? o : extreme2<MINIMISE>(m, o);
     }
     return m;
 }
+__device__ __forceinline__ int wave_imax(int v)
+{
+    v = row_imax(v);
+    int m = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++) {
+        const int o = __builtin_amdgcn_readlane(v, row * 16);
+        m = row == 0 ? o : max(m, o);
+    }
+    return m;
+}
+
+/* best (v, k) of the wave, in all its lanes: the extreme value first, then the largest index among
+ * the lanes that hold it (LIBSVM's tie rule).  Lanes without a candidate (k < 0) carry the neutral
+ * value (-inf for a maximum, +inf for a minimum). */
+template <bool MINIMISE>
+__device__ __forceinline__ void wave_select(double &v, int &k)
+{
+    const double m = wave_extreme<MINIMISE>(v);
+    k = wave_imax((k >= 0 && v == m) ? k : -1);
+    v = m;
+}
+
+/* the same over one row of 16 lanes; also returns the lane (0..15 within the row) that holds the winner */
+template <bool MINIMISE>
+__device__ __forceinline__ int row_select(double &v, int &k)
+{
+    const double m = row_extreme<MINIMISE>(v);
+    const int kb = row_imax((k >= 0 && v == m) ? k : -1);
+    const unsigned long long holders = __ballot(k == kb && v == m);
+    const unsigned row_mask = (unsigned)(holders >> ((threadIdx.x & 48))) & 0xFFFFu; /* this lane's row */
+    v = m;
+    k = kb;
+    return row_mask ? __builtin_ctz(row_mask) : 0;
+}
+
+__device__ __forceinline__ double row_max(double v) { return row_extreme<false>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_extreme<false>(v); }
 
 __global__ void k_diag(const double *__restrict__ K, int64_t ld, int n, double *__restrict__ diag)
 {
@@ -236,10 +260,11 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         }
         __syncthreads();
         /* the NW wave winners: one per lane of a row, DPP selection, then one broadcast read */
-        double wv = candA[lane & (NW - 1)].v;
-        int wk = candA[lane & (NW - 1)].k, ww = lane & (NW - 1);
-        row_select<false>(wv, wk, ww);
-        const Cand ci = candA[ww];
+        int wk = candA[lane & (NW - 1)].k;
+        double wv = wk >= 0 ? candA[lane & (NW - 1)].v : -INFINITY;
+        const int ww = row_select<false>(wv, wk) & (NW - 1);
+        Cand ci = candA[ww];
+        ci.k = wk; /* -1 when no wave has a candidate */
         PROF(1)
         const int i = ci.k;
         if (i < 0) break;
@@ -289,11 +314,11 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
                                    (double)((yi > 0.0) == (mk < n0) ? kfi[r] : -kfi[r]), mk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
-        wv = candB[lane & (NW - 1)].v;
         wk = candB[lane & (NW - 1)].k;
-        ww = lane & (NW - 1);
-        row_select<true>(wv, wk, ww);
-        const Cand cj = candB[ww];
+        wv = wk >= 0 ? candB[lane & (NW - 1)].v : INFINITY;
+        const int wj = row_select<true>(wv, wk) & (NW - 1);
+        Cand cj = candB[wj];
+        cj.k = wk;
         const double Gmax2 = row_max(g2s[lane & (NW - 1)]);
         PROF(3)
         const int j = cj.k;
