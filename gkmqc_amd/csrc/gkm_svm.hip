@@ -75,7 +75,8 @@ __device__ __forceinline__ bool better(double v, int k, double bv, int bk)
 template <int CTRL>
 __device__ __forceinline__ int dpp_i(int x)
 {
-    return __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+    /* every lane has a valid source under these controls: no 'old' value, so no register copy */
+    return __builtin_amdgcn_mov_dpp(x, CTRL, 0xf, 0xf, true);
 }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double x)
@@ -252,11 +253,12 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         wave_select<false>(bv, bk);
         if (bk < 0) {
             if (lane == 0) candA[wave].k = -1;
-        } else if ((bk & 63) == lane) { /* k = tid + r T, T a multiple of 64: the owner is lane k % 64 */
-            const int rr = (bk - tid) / T;
+        } else { /* k = tid + r T with T a multiple of 64: the owner is lane k % 64 and r = k / T for the whole wave */
+            const int rr = __builtin_amdgcn_readfirstlane(bk) / T; /* wave-uniform: one of the blocks below runs */
+            const bool owner = (bk & 63) == lane;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr) candA[wave] = {bv, al[r], (bk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
+                if (r == rr && owner) candA[wave] = {bv, al[r], (bk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
         __syncthreads();
         /* the NW wave winners: one per lane of a row, DPP selection, then one broadcast read */
@@ -305,11 +307,12 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         if (lane == 0) g2s[wave] = g2max;
         if (mk < 0) {
             if (lane == 0) candB[wave].k = -1;
-        } else if ((mk & 63) == lane) {
-            const int rr = (mk - tid) / T;
+        } else {
+            const int rr = __builtin_amdgcn_readfirstlane(mk) / T;
+            const bool owner = (mk & 63) == lane;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr)
+                if (r == rr && owner)
                     candB[wave] = {mv, al[r], (mk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r],
                                    (double)((yi > 0.0) == (mk < n0) ? kfi[r] : -kfi[r]), mk, TAB ? 0 : gidx[TAB ? 0 : r]};
         }
@@ -329,39 +332,34 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         const double Qij = cj.q, QDj = TAB ? qd_s[j] : cj.qd;
         double ai = ci.alpha, aj = cj.alpha;
         const double old_i = ai, old_j = aj;
-        if (yi != yj) {
-            double quad = QDi + QDj + 2 * Qij;
-            if (quad <= 0) quad = SVM_TAU;
-            const double delta = (-ci.G - cj.G) / quad;
-            const double diff = ai - aj;
-            ai += delta;
+        {
+            /* LIBSVM's two branches (y_i != y_j / y_i == y_j) differ in signs and in which bound is
+             * tested first; written with selects (negation is exact, a - b == a + (-b)), so the wave
+             * executes ~60 instructions instead of both branchy variants with their register copies */
+            const bool opp = yi != yj;
+            const double q2 = 2 * Qij;
+            double quad = (QDi + QDj) + (opp ? q2 : -q2);
+            quad = quad <= 0 ? SVM_TAU : quad;
+            const double delta = ((opp ? -ci.G : ci.G) - cj.G) / quad;
+            const double diff = ai - aj, sum = ai + aj;
+            ai += opp ? delta : -delta;
             aj += delta;
-            if (diff > 0) {
-                if (aj < 0) { aj = 0; ai = diff; }
-            } else {
-                if (ai < 0) { ai = 0; aj = -diff; }
+            const bool c1 = opp ? diff > 0 : sum > C;
+            /* first clipping */
+            {
+                const bool hit = opp ? (c1 ? aj < 0 : ai < 0) : (c1 ? ai > C : aj < 0);
+                const double ni = opp ? (c1 ? diff : 0.0) : (c1 ? C : sum);
+                const double nj = opp ? (c1 ? 0.0 : -diff) : (c1 ? sum - C : 0.0);
+                ai = hit ? ni : ai;
+                aj = hit ? nj : aj;
             }
-            if (diff > 0) { /* C_i - C_j = 0 */
-                if (ai > C) { ai = C; aj = C - diff; }
-            } else {
-                if (aj > C) { aj = C; ai = C + diff; }
-            }
-        } else {
-            double quad = QDi + QDj - 2 * Qij;
-            if (quad <= 0) quad = SVM_TAU;
-            const double delta = (ci.G - cj.G) / quad;
-            const double sum = ai + aj;
-            ai -= delta;
-            aj += delta;
-            if (sum > C) {
-                if (ai > C) { ai = C; aj = sum - C; }
-            } else {
-                if (aj < 0) { aj = 0; ai = sum; }
-            }
-            if (sum > C) {
-                if (aj > C) { aj = C; ai = sum - C; }
-            } else {
-                if (ai < 0) { ai = 0; aj = sum; }
+            /* second clipping */
+            {
+                const bool hit = opp ? (c1 ? ai > C : aj > C) : (c1 ? aj > C : ai < 0);
+                const double ni = opp ? (c1 ? C : C + diff) : (c1 ? sum - C : 0.0);
+                const double nj = opp ? (c1 ? C - diff : C) : (c1 ? C : sum);
+                ai = hit ? ni : ai;
+                aj = hit ? nj : aj;
             }
         }
         const double dai = ai - old_i, daj = aj - old_j;
@@ -372,11 +370,15 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) kj[r] = Kj[GI(r)];
         const double ci_ = yi * dai, cj_ = yj * daj;
+        const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
+        const int ri = iu / T, rj = ju / T;
+        const bool mine_i = (iu & (T - 1)) == tid, mine_j = (ju & (T - 1)) == tid;
 #pragma unroll
         for (int r = 0; r < SVM_R; r++) { /* (lanes past l update a gradient nobody reads) */
-            const int k = tid + r * T;
             G[r] += (double)kfi[r] * ci_ + (double)(float)kj[r] * cj_;
-            al[r] = k == i ? ai : k == j ? aj : al[r];
+            /* (i and j are wave-uniform: scalar tests pick the one register each of them lives in) */
+            if (r == ri) al[r] = mine_i ? ai : al[r];
+            if (r == rj) al[r] = mine_j ? aj : al[r];
         }
         PROF(4)
     }
