@@ -19,3 +19,15 @@ def test_random_parameter_sweep(built, seed, monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", ["fuzz_parity.py", "--seconds", "12", "--seed", str(seed)])
     mod.main()                                   # raises SystemExit with the failing case on a mismatch
     assert "fuzz ok" in capsys.readouterr().out
+
+
+@pytest.mark.gpu
+def test_random_svm_problems(built, monkeypatch, capsys):
+    """tools/fuzz_svm.py: random kernels, sizes, class balance, C, tol, duplicated samples -- the GPU
+    C-SVC bit-identical to scikit-learn (726 cases in the hand-run sweep of round 1)."""
+    spec = importlib.util.spec_from_file_location("fuzz_svm", os.path.join(ROOT, "tools", "fuzz_svm.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["fuzz_svm.py", "--seconds", "15", "--seed", "21"])
+    mod.main()
+    assert "svm fuzz ok" in capsys.readouterr().out
