@@ -510,7 +510,12 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
     /* fewest threads and registers that hold the largest problem: narrower reductions, fewer waves
      * per barrier, no spills (GKM_SVM_SHAPE=<threads>x<samples per thread> overrides, for timing) */
-    const int max_iter = 10000000;
+    /* LIBSVM's classic cap max(10^7, 100 l) is 10^7 for every size this kernel takes; scikit-learn runs
+     * without a cap (max_iter = -1), so a fold that stops here (iters < 0) has NOT converged the way the
+     * reference would: the callers re-solve such folds with scikit-learn (gkmqc_amd/svmcv.py).
+     * GKM_SVM_MAX_ITER lowers the cap (tests). */
+    int max_iter = 10000000;
+    if (const char *mi = getenv("GKM_SVM_MAX_ITER")) if (atoi(mi) > 0) max_iter = atoi(mi);
     int T = 0, R = 0;
     const char *force = getenv("GKM_SVM_SHAPE");
     if (force) sscanf(force, "%dx%d", &T, &R);

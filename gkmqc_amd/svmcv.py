@@ -97,7 +97,8 @@ def train_folds(K, trains, y, C=1.0, tol=1e-3):
         rho = d_rho.cpu().numpy()
         iters = d_it.cpu().numpy()
     if (iters < 0).any():
-        logging.warning("SMO hit the iteration cap in %d fold(s)", int((iters < 0).sum()))
+        # scikit-learn (max_iter=-1) would have kept iterating: these folds are not the reference's solution
+        logging.warning("SMO stopped at the iteration cap in %d fold(s)", int((iters < 0).sum()))
     sol = FoldSolutions(idx, n0, [alpha[off[f]:off[f + 1]] for f in range(len(idx))],
                         [grad[off[f]:off[f + 1]] for f in range(len(idx))], rho, iters)
     return sol, dict(idx=d_idx, off=off, n0=n0, alpha=d_alpha, rho=d_rho)
@@ -123,6 +124,14 @@ def decision_values(K, handles, tests):
         dec = d_dec.cpu().numpy()
     # sklearn flips the sign of LIBSVM's decision value for a two-class problem
     return [-dec[toff[f]:toff[f + 1]] for f in range(len(tests))]
+
+
+def device_block(K, rows, cols):
+    """K[rows][:, cols] of the device matrix (torch tensor), still on the device."""
+    import torch
+    r = torch.as_tensor(np.asarray(rows), device=K.device, dtype=torch.long)
+    c = torch.as_tensor(np.asarray(cols), device=K.device, dtype=torch.long)
+    return K.index_select(0, r).index_select(1, c)
 
 
 def crossValidate(args_svm, K, n_pseqs, n_nseqs):
@@ -157,6 +166,17 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
     logging.info("cross-validation on the GPU: %d folds (%d distinct)", len(trains), len(uniq))
     sol, handles = train_folds(K, u_trains, y, regularization, precision)
     scores = decision_values(K, handles, u_tests)
+    capped = [f for f in range(len(u_trains)) if sol.iters[f] < 0]
+    if capped:   # not converged within 10^7 iterations: the reference's solver has no cap, so use it for these folds
+        from sklearn.svm import SVC
+        logging.warning("%d fold(s) re-solved with scikit-learn (iteration cap of the GPU solver)", len(capped))
+        for f in capped:
+            tr, te = u_trains[f], u_tests[f]
+            ktr = device_block(K, tr, tr).cpu().numpy()
+            kte = device_block(K, te, tr).cpu().numpy()
+            sv = SVC(kernel="precomputed", C=regularization, tol=precision, shrinking=False, cache_size=_cache)
+            scores[f] = sv.fit(ktr, y[tr]).decision_function(kte)
+            sol.alpha[f] = np.abs(sv.dual_coef_[0])     # (only its sum is used below)
     u_auc = []
     for f, (test, score) in enumerate(zip(u_tests, scores)):
         auc = roc_auc_score(y[test], score)

@@ -35,7 +35,9 @@ extern "C" {
  *   C, eps       box constraint and stopping tolerance (sklearn `C`, `tol`)
  *   alpha, grad  out, device, same layout as idx: dual variables (0..C) and final gradient
  *   rho          out, device, nprob doubles
- *   iters        out, device, nprob ints (negative: iteration cap hit)
+ *   iters        out, device, nprob ints; NEGATIVE when the fold stopped at the iteration cap (10^7, LIBSVM's
+ *                classic default; scikit-learn has none): that fold has not converged and must be re-solved
+ *                by the caller if the reference's result is wanted
  * Returns 0 on success (work enqueued on `stream`).
  */
 int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob, const int *idx, const int64_t *off,

@@ -124,6 +124,19 @@ def test_main_uses_the_gpu_solver(built, tmp_path):
         assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
 
 
+def test_iteration_cap_falls_back_to_sklearn(built, monkeypatch):
+    """scikit-learn has no iteration cap, the GPU solver stops at 10^7 (LIBSVM's classic default) and says
+    so; the cross-validation then re-solves that fold with scikit-learn.  Forced here with a tiny cap."""
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    a = list(case["args_gkm"])
+    a[7], a[8] = POS, NEG
+    Kd, n_pos, n_neg = gkmsvm.computeGkmKernel(a, resident=True)
+    monkeypatch.setenv("GKM_SVM_MAX_ITER", "7")
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), Kd, n_pos, n_neg)
+    assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
+
+
 def test_bad_arguments_fail_loudly(built):
     import torch
     from gkmqc_amd import svmcv
