@@ -333,7 +333,7 @@ constexpr int BS_TK = BS_TRIP / 64;
 constexpr int BS_CAP = BS_TRIP + 64;
 constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 #ifndef GKM_BS_DU
-#define GKM_BS_DU 3 /* A/B on config 2: 2 -> 114.9 ms, 3 -> 114.8, 5 -> 118.0, 10 -> 117.9 */
+#define GKM_BS_DU 2 /* A/B on config 2 (final kernel, same box): 1 -> 84.9 ms, 2 -> 84.3, 3 -> 85.2, 4..6 -> 85.3 */
 #endif
 #ifndef GKM_BS_WAVES
 #define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
