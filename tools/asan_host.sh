@@ -1,0 +1,14 @@
+#!/bin/bash
+# AddressSanitizer + UBSan over the host-side C code (FASTA reader, weight tables) on the CPU:
+# the golden FASTA files and 12 000 random mutations of them (bytes flipped, '>' / LF / CR
+# inserted, truncation).  GPU sanitizers are not available on the pool; this covers the code
+# that parses untrusted input.       bash tools/asan_host.sh
+set -e
+cd "$(dirname "$0")/.."
+gcc -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -std=gnu11 -Iinclude -o /tmp/gkm_asan_host \
+    tools/asan_host.c gkmqc_amd/csrc/gkm_host.c -lm
+for pair in "quirks_pos.fa quirks_neg.fa" "motif_pos.fa motif_neg.fa"; do
+  set -- $pair
+  /tmp/gkm_asan_host tests/golden/$1 tests/golden/$2
+done
+echo "asan/ubsan: clean"
