@@ -11,4 +11,7 @@ for pair in "quirks_pos.fa quirks_neg.fa" "motif_pos.fa motif_neg.fa"; do
   set -- $pair
   /tmp/gkm_asan_host tests/golden/$1 tests/golden/$2
 done
+g++ -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -std=c++17 -Iinclude -o /tmp/gkm_asan_bitslice \
+    tools/asan_bitslice.cpp gkmqc_amd/csrc/bitslice_cpu_probe.cpp
+/tmp/gkm_asan_bitslice
 echo "asan/ubsan: clean"
