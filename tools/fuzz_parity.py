@@ -45,9 +45,11 @@ def main():
         M, H = int(rng.integers(1, 256)), float(rng.integers(1, 200))
         gamma = float(rng.choice([0.5, 1.0, 2.0]))
         n = int(rng.integers(2, 90))
-        mode = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+        mode = int(rng.choice([0, 0, 5, 5, 5, 1, 2, 3, 4]))
         if mode == 0:
             lens = np.full(n, int(rng.integers(L, 700)))
+        elif mode == 5:   # fixed lengths that fill one lane piece each: the one-piece-per-lane kernel variant
+            lens = np.full(n, int(rng.choice([int(rng.integers(170, 321)), int(rng.integers(500, 641)), 300, 600])))
         elif mode == 1:
             lens = rng.integers(L, 700, n)
         elif mode == 2:
