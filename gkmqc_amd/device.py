@@ -354,7 +354,7 @@ def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, w
             sq = torch.zeros(n, dtype=torch.float64, device=dev)
             ctx.gram_rows(np.arange(n), G.data_ptr(), n, P.data_ptr() if want_profiles else None, n, False, stream)
             ctx.normalize(G.data_ptr(), n, sq.data_ptr(), symmetric, stream)
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream().synchronize()   # (this stream only: others may carry unrelated work)
             return dict(K=G, P=P, sqnorm=sq, kernel=ctx.last_kernel_name(), ms=ctx.last_kernel_ms(),
                         comparisons=ctx.last_comparisons())
     finally:

@@ -69,3 +69,20 @@ def test_init_writes_the_eval_line(built, tmp_path):
     line = open(out + ".gkmqc.eval.out").read().rstrip("\n").split("\t")
     assert line[0] == POS and line[1] == NEG and int(line[2]) == case["n_pos"]
     assert abs(float(line[3]) - case["auc_mean"]) < 1e-9 and abs(float(line[4]) - case["auc_std"]) < 1e-9
+
+
+@pytest.mark.gpu
+def test_init_many_overlaps_and_matches_init(built, tmp_path):
+    """Several subsets in a row, the cross-validation of one on a second stream beside the matrix of the
+    next: same AUCs and the same eval lines as one `init` per subset."""
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    base = ["-s", "7", "-v", "0", "-t", "4", "-L", "10", "-k", "6", "-d", "3", "-r", "2"]
+    a1 = gkmsvm.build_parser().parse_args(["-p", POS, "-n", NEG, "-w", str(tmp_path / "seq")] + base)
+    a2 = gkmsvm.build_parser().parse_args(["-p", POS, "-n", NEG, "-w", str(tmp_path / "ovl")] + base)
+    pairs = [(POS, NEG), (NEG, POS), (POS, NEG), (NEG, POS)]
+    want = [gkmsvm.init(p, n, a1) for p, n in pairs]
+    got = gkmsvm.init_many(pairs, a2)
+    assert got == want
+    assert abs(got[0][0] - case["auc_mean"]) < 1e-12
+    assert open(str(tmp_path / "seq") + ".gkmqc.eval.out").read() == open(str(tmp_path / "ovl") + ".gkmqc.eval.out").read()
