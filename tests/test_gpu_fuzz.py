@@ -28,6 +28,7 @@ def test_random_svm_problems(built, monkeypatch, capsys):
     spec = importlib.util.spec_from_file_location("fuzz_svm", os.path.join(ROOT, "tools", "fuzz_svm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
+    monkeypatch.setenv("GKM_SVM_MAX_ITER", "300000")     # a pathological draw is skipped after ~2 s instead of running 10^7 iterations
     monkeypatch.setattr(sys, "argv", ["fuzz_svm.py", "--seconds", "15", "--seed", "21"])
     mod.main()
     assert "svm fuzz ok" in capsys.readouterr().out
