@@ -1,6 +1,6 @@
 """A short randomised parity sweep (tools/fuzz_parity.py: random kernel type, L, k, d, M, H, length
 distributions incl. duplicates / poly-A / reverse complements) as part of the GPU suite.  Longer
-sweeps were run by hand on the box: about 1 650 cases / 3 300 kernel runs without a mismatch."""
+sweeps were run by hand on the box: about 2 000 cases / 4 000 kernel runs without a mismatch."""
 import importlib.util
 import os
 import sys
@@ -24,7 +24,7 @@ def test_random_parameter_sweep(built, seed, monkeypatch, capsys):
 @pytest.mark.gpu
 def test_random_svm_problems(built, monkeypatch, capsys):
     """tools/fuzz_svm.py: random kernels, sizes, class balance, C, tol, duplicated samples -- the GPU
-    C-SVC bit-identical to scikit-learn (726 cases in the hand-run sweep of round 1)."""
+    C-SVC bit-identical to scikit-learn (about 3 300 cases in the hand-run sweeps of round 1)."""
     spec = importlib.util.spec_from_file_location("fuzz_svm", os.path.join(ROOT, "tools", "fuzz_svm.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
