@@ -1,35 +1,53 @@
 #!/usr/bin/env python3
 """bench.py -- gkm kernel pairs/sec (N=10k, 300 bp, L=11, k=7, d=3) on N GPUs of one node.
 
-One "step" = one complete pass of the hot path over the synthetic problem with the
-sequences already resident in HBM: build the per-call row tables, run the Gram kernel for
-this rank's rows, all-gather the row slabs over RCCL (world_size > 1), normalise the
-assembled matrix (division by the self norms, unit diagonal) on every rank.
+One "step" = one complete pass of the hot path over the synthetic problem with the sequences
+already resident in HBM: build the per-call row tables, run the Gram kernel for this rank's rows,
+all-gather the row slabs over RCCL (N > 1), normalise the assembled matrix (division by the self
+norms, unit diagonal) on every rank.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|peaks|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
+(fresh child processes, one per GPU, before anything in this process has touched the GPU) and relays
+rank 0's line.  `--assembly cabi` instead runs the one-process entry of the C ABI
+(gkmhip_gram_allgather: one host thread per device, RCCL all-gather) as a cross-check.
+
 Rank 0 prints ONE JSON line.  `value` = N(N-1)/2 pairs / (max-over-ranks seconds per step).
-The total work is fixed as the GPU count grows (the N x N matrix is sharded by row block),
-so `scaling` is "strong".
+The total work is fixed as the GPU count grows (the N x N matrix is sharded by row block), so
+`scaling` is "strong".
 """
 import argparse
+import glob
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import tempfile
 import time
 
-import numpy as np
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# Integer-VALU peak of MI355X: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78 643 Gop/s.
-# (tools/valu_peak.hip measures 65-72 Tera lane-ops/s for full-rate VOP2 ops on the box, i.e. a
-# wave64 v_xor_b32 every ~2.2 cycles per SIMD; SURVEY.md §8(d) assumed 16 lanes/clk = 39 321.)
+# Integer-VALU peak of MI355X: 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = 78 643 Gop/s (lane-ops: one
+# 32-bit operation of one lane).  tools/valu_peak.hip measures what a pure v_bitop3_b32 / v_xor_b32 stream
+# sustains on the box (profiles/*valu_peak*): both are reported.
 PEAK_INT32_GOPS = 256 * 4 * 32 * 2.4
 OPS_PER_COMPARISON = 6            # op model of SURVEY.md §8(d): xor, shift, or, and, popcount, compare
+KERNEL_SOURCES = ("gkmqc_amd/csrc/gkm_device.hip", "gkmqc_amd/csrc/gkm_bitslice.h", "gkmqc_amd/csrc/gkm_pack.h")
+
+# name: (n_pos, n_neg, length, length_range, kernel_type, L, k, d, generator, label)
+WORKLOADS = {
+    "c2": (5000, 5000, 300, None, 4, 11, 7, 3, "iid", "configs[1]"),
+    "c1": (200, 200, 300, None, 2, 10, 6, 3, "iid", "configs[0]"),
+    "c3": (10000, 10000, 300, None, 4, 11, 7, 3, "iid", "configs[2]"),
+    "c5": (5000, 5000, 300, (150, 600), 4, 12, 8, 4, "iid", "configs[4] on one GPU"),
+    # configs[3] stand-in: ONE subset of `gkmqc.py evaluate` at its real size and parameters (reference
+    # bin/gkmqc.py:150-154,181-185) on peak-like synthetic sequences (gkmqc_amd/synth.py); the genome is not here
+    "peaks": (5000, 5000, 600, None, 4, 10, 6, 3, "peaks", "configs[3] stand-in (one evaluate subset)"),
+}
 
 
 def host_cores():
@@ -49,80 +67,217 @@ def host_cores():
     return cores
 
 
-def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
-    (separate FETCH_SIZE / WRITE_SIZE passes, tools/collect_profiles.sh); None if absent."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    if not files:
-        return None, None
+def cpu_model():
     try:
-        d = json.load(open(files[-1]))
-        return d.get("hbm_bytes_per_launch"), os.path.basename(files[-1])
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None, None
+        pass
+    return "unknown"
 
 
-def measured_valu_insts():
-    """SQ_INSTS_VALU (wave instructions) per launch of the dominant kernel from the same summary."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_summary.json")))
-    try:
-        return json.load(open(files[-1]))["per_launch"]["SQ_INSTS_VALU"]
-    except Exception:
-        return None
+def kernel_source_hash():
+    """Identifies the hot kernel's code: a PMC summary taken on other code must not be used."""
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()
 
 
-def cpu_baseline(args, L, k, d, kernel_type):
+def pmc_summary(workload):
+    """Per-launch rocprofv3 counters of the dominant kernel for THIS workload and THIS kernel source
+    (profiles/r*_pmc_*.json written by tools/summarize_profiles.py).  -> (dict or None, why)."""
+    want = kernel_source_hash()
+    stale = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_*.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload", "c2") != workload:
+            continue
+        if d.get("kernel_source_sha256") == want:
+            return d, os.path.basename(path)
+        stale = stale or os.path.basename(path)
+    if stale:
+        return None, "stale: %s was taken on other kernel code (re-run tools/collect_profiles.sh)" % stale
+    return None, "no PMC summary for workload %s under profiles/" % workload
+
+
+def measured_valu_peak():
+    """Lane-ops/s a pure full-rate VALU stream sustains on the box (tools/valu_peak.hip), Gop/s."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_peak.json")), reverse=True):
+        try:
+            return float(json.load(open(path))["best_full_rate_Gops"]), os.path.basename(path)
+        except Exception:
+            continue
+    return None, None
+
+
+def make_problem(args):
+    from gkmqc_amd import synth
+    if args.generator == "peaks":
+        return (synth.make_peak_sequences(11, args.n_pos, args.length, True) +
+                synth.make_peak_sequences(12, args.n_neg, args.length, False))
+    lr = tuple(args.length_range) if args.length_range else None
+    return synth.make_sequences(1, args.n_pos, args.length, lr) + synth.make_sequences(2, args.n_neg, args.length, lr)
+
+
+def write_problem_files(args, n_pos, n_neg, tmp):
+    from gkmqc_amd import synth
+    pf, nf = os.path.join(tmp, "p.fa"), os.path.join(tmp, "n.fa")
+    if args.generator == "peaks":
+        synth.write_peak_problem(pf, nf, n_pos, n_neg, args.length)
+    else:
+        synth.write_problem(pf, nf, n_pos, n_neg, args.length, tuple(args.length_range) if args.length_range else None)
+    return pf, nf
+
+
+def cpu_baseline(args):
     """The reference's own CPU path (oracle/_ref, unmodified sources built by oracle/Makefile)
     timed on this box's host cores on a bounded sample of the same workload; falls back to
     the C restatement (kind "port") if the reference build did not travel."""
-    from gkmqc_amd import synth
     from oracle import oracle as O
     cores = host_cores()
-    npos = nneg = args.cpu_sample
+    npos = min(args.cpu_sample, args.n_pos)
+    nneg = min(args.cpu_sample, args.n_neg)
     tmp = tempfile.mkdtemp(prefix="gkm_bench_")
-    pf, nf = os.path.join(tmp, "p.fa"), os.path.join(tmp, "n.fa")
-    synth.write_problem(pf, nf, npos, nneg, args.length)
-    n = npos + nneg
     if O.have_ref():
         kind, fn = "reference", O.ref_pywrapper
     else:
         kind, fn = "port", O.oracle_pywrapper
-        npos = nneg = min(args.cpu_sample, 150)   # brute-force port: keep it to seconds
-        synth.write_problem(pf, nf, npos, nneg, args.length)
-        n = npos + nneg
-    opt = O.make_opt(kernel_type, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=cores, verbosity=0)
+        npos = nneg = min(npos, 150)   # brute-force port: keep it to seconds
+    pf, nf = write_problem_files(args, npos, nneg, tmp)
+    n = npos + nneg
+    opt = O.make_opt(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, pf, nf, nthreads=cores, verbosity=0)
     t0 = time.time()
     rc, _, _, _ = fn(opt, n)
     wall = time.time() - t0
     assert rc == 0
+    whole = (npos, nneg) == (args.n_pos, args.n_neg)
     return {"value": (n * (n - 1) / 2) / wall, "unit": "pairs/s", "cores": cores, "kind": kind,
-            "sample": "%d+%d x %d bp synthetic, same parameters, whole gkm_main_pywrapper call "
-                      "(FASTA read + tree + rows), %d row threads, %.1f s wall; the reference's "
-                      "pairs/s rises with N (N=10k on 8 cores: 218 s = 229 k pairs/s, BASELINE.md)"
-                      % (npos, nneg, args.length, cores, wall)}
+            "n_sequences": n, "headline_workload": whole, "wall_s": wall, "cpu_model": cpu_model(),
+            "sample": "%s: %d+%d x %d bp, same generator and parameters, whole gkm_main_pywrapper call "
+                      "(FASTA read + tree + rows), %d row threads, %.1f s wall%s"
+                      % ("the WHOLE workload" if whole else "bounded sample", npos, nneg, args.length, cores, wall,
+                         "" if whole else "; the reference's pairs/s rises with N -- the full-N same-box run is "
+                         "profiles/r2_cpu_baseline_full.json (bench.py --cpu-sample 5000)")}
 
 
-def main():
+def end_to_end(args, dev):
+    """The two PCIe-inclusive walls SURVEY.md §8(d) asks for beside the device-resident `value`, each
+    from FASTA files on disk, each measured on a warm second call (the first one pays HIP start-up):
+      boundary_ms  one gkm_main_pywrapper call (reference src/gkmkern_pylib.c:92-246): entry -> the
+                   caller's pageable row pointers hold the lower triangle
+      pipeline_ms  gkmqc_amd.gkmsvm.main: FASTA -> matrix in HBM -> 5-fold C-SVC cross-validation -> AUC
+    """
+    import ctypes
+    import numpy as np
+    from gkmqc_amd import device, gkmsvm
+    tmp = tempfile.mkdtemp(prefix="gkm_e2e_")
+    pf, nf = write_problem_files(args, args.n_pos, args.n_neg, tmp)
+    n = args.n_pos + args.n_neg
+    out = {}
+    kmat = np.zeros((n, n))
+    rows = (kmat.ctypes.data + np.arange(n) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.zeros(2, dtype=np.int32)
+    opt = device.gkmOpt(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, os.fsencode(pf), os.fsencode(nf),
+                        host_cores(), 0)
+    walls = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rc = device.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data)
+        walls.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0 and int(sizes[0]) == args.n_pos
+    out["boundary_ms"] = min(walls[1:])
+    out["boundary_first_call_ms"] = walls[0]
+    out["boundary_pairs_per_s"] = (n * (n - 1) / 2) / (out["boundary_ms"] * 1e-3)
+    assert kmat[n - 1, n - 1] == 1.0 and kmat[n - 1, 0] != 0.0 and kmat[0, n - 1] == 0.0
+    del kmat, rows
+    argv = ["-p", pf, "-n", nf, "-w", os.path.join(tmp, "e2e"), "-t", str(args.kernel_type), "-L", str(args.L),
+            "-k", str(args.k), "-d", str(args.d), "-s", "1", "-v", "0"]
+    walls, auc = [], None
+    for _ in range(2):
+        t0 = time.perf_counter()
+        auc, _std = gkmsvm.main(argv)
+        walls.append((time.perf_counter() - t0) * 1e3)
+    out["pipeline_ms"] = walls[-1]
+    out["pipeline_first_call_ms"] = walls[0]
+    out["pipeline_auc"] = float(auc)
+    out["note"] = ("warm calls from FASTA on disk; boundary = gkm_main_pywrapper into pageable numpy rows (PCIe "
+                   "+ host scatter included, %d helper threads); pipeline = FASTA -> Gram matrix in HBM -> 5-fold "
+                   "C-SVC cross-validation on the GPU -> AUC; neither is `value`" % host_cores())
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n-pos", type=int, default=5000)
-    ap.add_argument("--n-neg", type=int, default=5000)
-    ap.add_argument("--length", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS),
+                    help="c2 = BASELINE configs[1] (the headline metric); peaks = configs[3] stand-in")
+    ap.add_argument("--n-pos", type=int, default=None)
+    ap.add_argument("--n-neg", type=int, default=None)
+    ap.add_argument("--length", type=int, default=None)
     ap.add_argument("--length-range", type=int, nargs=2, default=None, help="uniform random lengths (config 5: 150 600)")
-    ap.add_argument("--kernel-type", type=int, default=4)
-    ap.add_argument("-L", type=int, default=11)
-    ap.add_argument("-k", type=int, default=7)
-    ap.add_argument("-d", type=int, default=3)
+    ap.add_argument("--kernel-type", type=int, default=None)
+    ap.add_argument("-L", type=int, default=None)
+    ap.add_argument("-k", type=int, default=None)
+    ap.add_argument("-d", type=int, default=None)
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "bitslice"])
-    ap.add_argument("--cpu-sample", type=int, default=1500, help="pos (=neg) sequences of the CPU baseline sample")
+    ap.add_argument("--assembly", default="torch", choices=["torch", "cabi"],
+                    help="N > 1: torch = one process per GPU, torch.distributed all-gather (default); "
+                         "cabi = one process, gkmhip_gram_allgather (one host thread per device)")
+    ap.add_argument("--cpu-sample", type=int, default=2000, help="pos (=neg) sequences of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the assembled matrix with a 1-GPU run (debug)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    w = WORKLOADS[args.workload]
+    custom = False
+    for i, name in enumerate(("n_pos", "n_neg", "length", "length_range", "kernel_type", "L", "k", "d")):
+        if getattr(args, name) is None:
+            setattr(args, name, w[i])
+        elif getattr(args, name) != w[i] and not (name == "length_range" and tuple(getattr(args, name)) == w[i]):
+            custom = True
+    args.generator, args.label = w[8], ("custom (from %s)" % args.workload if custom else w[9])
+    args.custom = custom
+    return args
 
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this
+    process has not imported torch nor touched the GPU, and it never replaces itself), relay rank 0's
+    stdout, fail if any rank fails."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    line, _ = procs[0].communicate()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(line.decode())
+    sys.stdout.flush()
+    return max(abs(c) for c in codes)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and args.assembly == "torch" and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, argv)
+    return run_rank(args)
+
+
+def run_rank(args):
     # stdout carries exactly one JSON line.  Libraries write there too (RCCL prints its version
     # banner on file descriptor 1 when stderr is not a file), so descriptor 1 is pointed at stderr
     # for the duration of the run and the line goes to a private copy of the real stdout.
@@ -130,14 +285,15 @@ def main():
     real_stdout = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from gkmqc_amd import device, sharding
-    from gkmqc_amd import synth
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cabi = args.assembly == "cabi" and args.gpus > 1
+    world = 1 if cabi else int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0")) if not cabi else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not cabi else 0
     # GKM_BENCH_FORCE_DIST=1: take the sharded path (process group, slabs, all-gather, permutation)
     # even with one rank -- exercises the real RCCL backend on a one-GPU box
     dist_on = world > 1 or os.environ.get("GKM_BENCH_FORCE_DIST") == "1"
@@ -149,14 +305,21 @@ def main():
                 sk.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    assert args.gpus == world, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run)"
+    if not cabi and args.gpus != world:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start the ranks with torch.distributed.run, or plainly as "
+                         "`python bench.py --gpus N` (it spawns them itself)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
     # Rehearsal knobs (not used by the driver): GKM_BENCH_BACKEND=gloo runs the collective through
     # host memory, GKM_BENCH_SHARE_GPU=1 puts every rank on GPU 0 -- lets the N>1 path be exercised
     # on a one-GPU box.
     backend = os.environ.get("GKM_BENCH_BACKEND", "nccl")
-    if os.environ.get("GKM_BENCH_SHARE_GPU") == "1":
+    share_gpu = os.environ.get("GKM_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if (world > ndev or (cabi and args.gpus > ndev)) and not share_gpu:
+        raise SystemExit("%d ranks but %d visible GPU(s); GKM_BENCH_SHARE_GPU=1 (with GKM_BENCH_BACKEND=gloo for "
+                         "--assembly torch) rehearses the N > 1 path on one GPU" % (max(world, args.gpus), ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if dist_on:
@@ -166,44 +329,68 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     # synthetic problem (identical on every rank), resident in HBM before timing starts
-    lr = tuple(args.length_range) if args.length_range else None
-    seqs = [device.encode(s) for s in synth.make_sequences(1, args.n_pos, args.length, lr) +
-            synth.make_sequences(2, args.n_neg, args.length, lr)]
+    seqs = [device.encode(s) for s in make_problem(args)]
     n = len(seqs)
-    ctx = device.GramContext(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, local_rank)
-    ctx.set_kernel({"auto": 0, "direct": 1, "bitslice": 2}[args.kernel])
     stream = torch.cuda.current_stream().cuda_stream
-    ctx.set_sequences(seqs, stream)
 
-    # Row sharding: folded row blocks per rank; with more than one rank the rank's rows are cut
-    # into interleaved chunks so that the RCCL all-gather of one chunk overlaps the kernel of the next.
-    chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4"))) if dist_on else 1
-    parts, pc = sharding.chunked_layout(n, world, rank, chunks)
-    full = torch.zeros((n, n), dtype=torch.float64, device=dev)
-    sq = torch.zeros(n, dtype=torch.float64, device=dev)
-    if dist_on:
-        slab = torch.zeros((chunks, pc, n), dtype=torch.float64, device=dev)
-        gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64, device=dev)
-        slot_of_row = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks)).to(dev)
+    if cabi:
+        import ctypes
+        devices = [0] * args.gpus if share_gpu else list(range(args.gpus))
+        ctxs = []
+        for dv in devices:
+            c = device.GramContext(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, dv)
+            c.set_kernel({"auto": 0, "direct": 1, "bitslice": 2}[args.kernel])
+            with torch.cuda.device(dv):
+                c.set_sequences(seqs, torch.cuda.current_stream().cuda_stream)
+            ctxs.append(c)
+        Ks = [torch.zeros((n, n), dtype=torch.float64, device=torch.device("cuda", dv)) for dv in devices]
+        for dv in set(devices):
+            torch.cuda.synchronize(dv)
+        handles = (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        outs = (ctypes.c_void_p * len(ctxs))(*[K.data_ptr() for K in Ks])
+        lib = device.load()
+        chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4")))
+        ctx, full = ctxs[0], Ks[0]
 
-    def compute(c, out_ptr, local, on=None):
-        if len(parts[c]):
-            ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream if on is None else on)
+        def step():
+            rc = lib.gkmhip_gram_allgather(handles, len(ctxs), outs, n, 0, chunks)
+            if rc:
+                raise SystemExit("gkmhip_gram_allgather: " + lib.gkmhip_last_error().decode())
+    else:
+        ctx = device.GramContext(args.kernel_type, args.L, args.k, args.d, 50, 50.0, 1.0, local_rank)
+        ctx.set_kernel({"auto": 0, "direct": 1, "bitslice": 2}[args.kernel])
+        ctx.set_sequences(seqs, stream)
 
-    # Two side streams, chunks alternate between them: the kernel of chunk c+1 fills the CUs that the
-    # drain of chunk c leaves idle, and its all-gather overlaps as before.
-    side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if dist_on else None
+        # Row sharding: folded row blocks per rank; with more than one rank the rank's rows are cut
+        # into interleaved chunks so that the RCCL all-gather of one chunk overlaps the kernel of the next.
+        chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4"))) if dist_on else 1
+        parts, pc = sharding.chunked_layout(n, world, rank, chunks)
+        full = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        sq = torch.zeros(n, dtype=torch.float64, device=dev)
+        if dist_on:
+            slab = torch.zeros((chunks, pc, n), dtype=torch.float64, device=dev)
+            gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64, device=dev)
+            slot_of_row = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks)).to(dev)
 
-    def step():
-        if not dist_on:
-            compute(0, full.data_ptr(), False)
-        else:
-            main = torch.cuda.current_stream()
+        def compute(c, out_ptr, local, on=None):
+            if len(parts[c]):
+                ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream if on is None else on)
+
+        # Two side streams, chunks alternate between them: the kernel of chunk c+1 fills the CUs that the
+        # drain of chunk c leaves idle, and its all-gather overlaps as before.
+        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if dist_on else None
+
+        def step():
+            if not dist_on:
+                compute(0, full.data_ptr(), False)
+                ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
+                return
+            main_s = torch.cuda.current_stream()
             pending = []
             for c in range(chunks):
                 st = side[c & 1]
                 if c < 2:
-                    st.wait_stream(main)        # the previous step has finished reading slab / gathered
+                    st.wait_stream(main_s)      # the previous step has finished reading slab / gathered
                 ctx.set_scratch_slot(c & 1)     # chunks c and c+2 share a slot and a stream
                 with torch.cuda.stream(st):
                     compute(c, slab[c].data_ptr(), True, st.cuda_stream)
@@ -216,15 +403,17 @@ def main():
             ctx.set_scratch_slot(0)
             for w in pending:
                 w.wait()
-            main.wait_stream(side[0])
-            main.wait_stream(side[1])
-            torch.index_select(gathered.view(chunks * world * pc, n), 0, slot_of_row, out=full)
-        ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
+            main_s.wait_stream(side[0])
+            main_s.wait_stream(side[1])
+            # un-permutation + normalisation in one pass over the gathered slabs
+            ctx.assemble_normalize(gathered.data_ptr(), n, slot_of_row.data_ptr(), full.data_ptr(), n, sq.data_ptr(),
+                                   False, stream)
 
     def barrier():
         if dist_on:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        for dv in range(torch.cuda.device_count()) if cabi else [dev]:
+            torch.cuda.synchronize(dv)
 
     for _ in range(args.warmup):
         step()
@@ -239,44 +428,67 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # dominant kernel: one extra launch bracketed by HIP events on the launch stream
-    # (recorded inside gkmhip_gram_rows), outside the wall-clock region
+    # dominant kernel: extra launches bracketed by HIP events on the launch stream (recorded inside
+    # gkmhip_gram_rows), outside the wall-clock region
     durs, comparisons = [], 0.0
-    for _ in range(max(3, min(args.steps, 5))):
-        ms, comparisons = 0.0, 0.0
-        for c in range(chunks):
-            if not len(parts[c]):
-                continue
-            compute(c, slab[c].data_ptr() if dist_on else full.data_ptr(), dist_on)
+    if cabi:
+        rows0 = np.concatenate(sharding.chunked_layout(n, args.gpus, 0, 1)[0])
+        buf = torch.zeros((len(rows0), n), dtype=torch.float64, device=dev)
+        for _ in range(3):
+            ctx.gram_rows(rows0, buf.data_ptr(), n, None, 0, True, stream)
             torch.cuda.synchronize(dev)
-            ms += ctx.last_kernel_ms()
-            comparisons += ctx.last_comparisons()   # 2 n_a n_j summed over this rank's (a, j<=a) pairs
-        durs.append(ms)
+            durs.append(ctx.last_kernel_ms())
+            comparisons = ctx.last_comparisons()
+        del buf
+    else:
+        for _ in range(max(3, min(args.steps, 5))):
+            ms, comparisons = 0.0, 0.0
+            for c in range(chunks):
+                if not len(parts[c]):
+                    continue
+                compute(c, slab[c].data_ptr() if dist_on else full.data_ptr(), dist_on)
+                torch.cuda.synchronize(dev)
+                ms += ctx.last_kernel_ms()
+                comparisons += ctx.last_comparisons()   # 2 n_a n_j summed over this rank's (a, j<=a) pairs
+            durs.append(ms)
     kern_ms = float(np.mean(durs))
     kname = ctx.last_kernel_name()
 
     if args.check:  # every rank recomputes the whole matrix alone and compares bit for bit
         step()
-        torch.cuda.synchronize(dev)
+        barrier()
         ref = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        sq2 = torch.zeros(n, dtype=torch.float64, device=dev)
         ctx.gram_rows(np.arange(n), ref.data_ptr(), n, None, 0, False, stream)
-        ctx.normalize(ref.data_ptr(), n, sq.data_ptr(), False, stream)
+        ctx.normalize(ref.data_ptr(), n, sq2.data_ptr(), False, stream)
         torch.cuda.synchronize(dev)
         same = bool((torch.tril(ref) == torch.tril(full)).all().item())
         print("rank %d: assembled matrix identical to single-GPU matrix: %s" % (rank, same), file=sys.stderr, flush=True)
         assert same
 
-    shape = (args.n_pos, args.n_neg, args.length, lr, args.L, args.k, args.d)
-    WORKLOAD_LABEL = {(5000, 5000, 300, None, 11, 7, 3): "configs[1]", (200, 200, 300, None, 10, 6, 3): "configs[0]",
-                      (10000, 10000, 300, None, 11, 7, 3): "configs[2]"}.get(shape, "custom")
+    n_gpus = args.gpus if cabi else world
     pairs = n * (n - 1) / 2
     sec_per_step = elapsed / args.steps
+    if cabi:
+        sharding_note = ("one process, %d host threads; folded row blocks in %d chunks, %s all-gather overlapped with "
+                         "the next chunk (gkmhip_gram_allgather)" % (args.gpus, chunks, device.load().gkmhip_last_transport().decode()))
+    elif dist_on:
+        sharding_note = ("one process per GPU; folded row blocks in %d interleaved chunks, %s all-gather overlapped with the "
+                         "next chunk" % (chunks, "RCCL" if backend == "nccl" else backend))
+    else:
+        sharding_note = "single GPU"
+    desc = ("%d pos + %d neg x %s bp %s, kernel type %d, L=%d k=%d d=%d, M=50 H=50; full lower-triangular Gram matrix + "
+            "normalisation" % (args.n_pos, args.n_neg,
+                               ("%d-%d" % tuple(args.length_range)) if args.length_range else str(args.length),
+                               "peak-like synthetic DNA (gkmqc_amd.synth.make_peak_sequences seeds 11/12)"
+                               if args.generator == "peaks" else "iid ACGT (splitmix64 seeds 1/2)",
+                               args.kernel_type, args.L, args.k, args.d))
     out = {
         "metric": "gkm kernel pairs/sec (N=%dk, %d bp, L=%d,k=%d,d=%d)" % (n // 1000, args.length, args.L, args.k, args.d)
         if n % 1000 == 0 else "gkm kernel pairs/sec (N=%d, %d bp, L=%d,k=%d,d=%d)" % (n, args.length, args.L, args.k, args.d),
         "value": pairs / sec_per_step,
         "unit": "pairs/s",
-        "n_gpus": world,
+        "n_gpus": n_gpus,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": sec_per_step * 1e3,
@@ -285,44 +497,58 @@ def main():
         "vs_baseline": None,
         "dtype": "u32",
         "data": "synthetic",
-        "config": {"workload": WORKLOAD_LABEL + ": %d pos + %d neg x %d bp iid ACGT (splitmix64 seeds 1/2), kernel type %d, "
-                               "L=%d k=%d d=%d, M=50 H=50; full lower-triangular Gram matrix + normalisation"
-                               % (args.n_pos, args.n_neg, args.length, args.kernel_type, args.L, args.k, args.d),
-                   "n_sequences": n, "row_sharding": ("folded row blocks in %d interleaved chunks, RCCL all-gather overlapped with the next chunk" % chunks) if dist_on else "single GPU",
-                   "kernel": kname},
+        "config": {"workload": args.label + ": " + desc, "n_sequences": n, "row_sharding": sharding_note, "kernel": kname,
+                   "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GKM_")}},
     }
     if rank == 0:
-        achieved = comparisons * OPS_PER_COMPARISON / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_src = (None, None)
-        insts = None
-        if world == 1 and (args.n_pos, args.n_neg, args.length, args.L, args.k, args.d, args.kernel_type) == (5000, 5000, 300, 11, 7, 3, 4):
-            traffic, traffic_src = measured_traffic()   # PMC numbers were taken on exactly this workload
-            insts = measured_valu_insts()
+        kern_s = kern_ms * 1e-3
+        algorithmic = comparisons * OPS_PER_COMPARISON / kern_s / 1e9
+        pmc, pmc_src = (None, "PMC summaries are kept for the single-GPU workloads only")
+        if n_gpus == 1 and not args.custom and args.kernel == "auto":
+            pmc, pmc_src = pmc_summary(args.workload)
+        insts = pmc["per_launch"].get("SQ_INSTS_VALU") if pmc else None
+        traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
+        executed = (insts * 64 / kern_s / 1e9) if insts else None
+        peak_meas, peak_src = measured_valu_peak()
         out["roofline"] = {
             "bound": "valu",
-            "achieved": achieved, "peak": PEAK_INT32_GOPS, "unit": "Gop/s", "frac": achieved / PEAK_INT32_GOPS,
-            "traffic": traffic, "traffic_source": traffic_src,
+            # EXECUTED lane-ops of the dominant kernel (rocprofv3 SQ_INSTS_VALU x 64 lanes, per launch, from the
+            # committed summary taken on this very kernel source and workload) over its live duration
+            "achieved": executed, "peak": PEAK_INT32_GOPS, "unit": "Gop/s",
+            "frac": (executed / PEAK_INT32_GOPS) if executed else None,
+            "peak_measured": peak_meas, "peak_measured_source": peak_src,
+            "frac_of_measured_peak": (executed / peak_meas) if executed and peak_meas else None,
+            "traffic": traffic, "pmc_source": pmc_src,
+            "hbm_achieved_GBps": (traffic / kern_s / 1e9) if traffic else None,
             "kernel": kname, "kernel_ms": kern_ms, "comparisons_per_launch": comparisons,
-            "hbm_achieved_GBps": (traffic / (kern_ms * 1e-3) / 1e9) if traffic else None,
-            # executed (not algorithmic) VALU work: rocprofv3 SQ_INSTS_VALU x 64 lanes over the live kernel time
-            "executed_valu_Gops": (insts * 64 / (kern_ms * 1e-3) / 1e9) if insts else None,
-            "executed_frac_of_peak": (insts * 64 / (kern_ms * 1e-3) / 1e9 / PEAK_INT32_GOPS) if insts else None,
+            "comparisons_per_s": comparisons / kern_s,
             "executed_insts_per_comparison": (insts * 64 / comparisons) if insts else None,
-            "note": "This path is integer-VALU bound, neither HBM nor MFMA (SURVEY.md §8(d)); bound says so. "
-                    "achieved = ALGORITHMIC ops: 6 int32 ops per l-mer comparison (SURVEY op model) x "
-                    "comparisons_per_launch (2 n_a n_j per pair, this rank's pairs) / kernel_ms (HIP events on the "
-                    "launch stream). peak = 256 CU x 4 SIMD x 32 lanes x 2.4 GHz. The bit-sliced kernel EXECUTES "
-                    "about 0.56 VALU instructions per comparison instead of 6, which is why frac exceeds 1: see DESIGN.md for "
-                    "the executed-instruction utilisation from rocprofv3 (profiles/). HBM traffic is incidental.",
+            # the op model of SURVEY.md §8(d) (6 int32 ops per l-mer comparison): what a comparison-by-comparison
+            # kernel would have to execute; the bit-sliced kernel executes ~10x fewer, so this "fraction" exceeds 1
+            "algorithmic_ops_per_comparison": OPS_PER_COMPARISON,
+            "algorithmic_Gops": algorithmic, "algorithmic_frac": algorithmic / PEAK_INT32_GOPS,
+            "note": "Integer-VALU bound, neither HBM nor MFMA (SURVEY.md §8(d)). frac = executed VALU lane-ops / peak "
+                    "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); null when the committed PMC summary was not taken on this "
+                    "kernel source + workload. kernel_ms: HIP events on the launch stream. HBM traffic is incidental.",
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, args.L, args.k, args.d, args.kernel_type)
+        if n_gpus == 1 and not args.no_end_to_end:
+            ctx.close()
+            del full
+            torch.cuda.empty_cache()
+            out["end_to_end"] = end_to_end(args, dev)
+        if n_gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), file=real_stdout, flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    if cabi:
+        for c in ctxs:
+            c.close()
+    else:
+        ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -201,3 +201,22 @@ extern "C" int bsprobe_profile_packed(int W, int L, int d, const uint8_t *codes,
     PCASE(5, 11, 3)
     return 1;
 }
+
+/* ---- row sharding layout (gkm_shard.h) for tests/test_sharding.py ---- */
+#include "gkm_shard.h"
+
+extern "C" int shardprobe_chunk_rows(int n, int world, int chunks) { return gkmshard::chunk_rows(n, world, chunks); }
+
+extern "C" int shardprobe_part(int n, int world, int rank, int chunks, int chunk, int *rows_out)
+{
+    const std::vector<std::vector<int>> parts = gkmshard::chunked_layout(n, world, rank, chunks);
+    const std::vector<int> &p = parts[(size_t)chunk];
+    for (size_t i = 0; i < p.size(); i++) rows_out[i] = p[i];
+    return (int)p.size();
+}
+
+extern "C" void shardprobe_gather_index(int n, int world, int chunks, int64_t *slot_out)
+{
+    const std::vector<int64_t> s = gkmshard::chunked_gather_index(n, world, chunks);
+    for (int i = 0; i < n; i++) slot_out[i] = s[(size_t)i];
+}

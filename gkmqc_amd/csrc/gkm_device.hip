@@ -55,12 +55,27 @@ static int set_err_msg(const std::string &m, int code)
     } while (0)
 
 extern "C" const char *gkmhip_last_error(void) { return g_err.c_str(); }
+/* (used by gkm_multi.hip so that one call reports every layer's failures) */
+extern "C" void gkmhip_set_error_message(const char *msg) { g_err = msg ? msg : ""; }
 
 extern "C" int gkmhip_device_count(void)
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
+}
+
+extern "C" int gkmhip_current_device(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+extern "C" int gkmhip_set_current_device(int device)
+{
+    HIPCHK(hipSetDevice(device));
+    return 0;
 }
 
 /* Pinned staging for device-to-host copies, kept for the life of the process: the pipeline
@@ -203,6 +218,9 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
 }
+
+extern "C" int gkmhip_n_sequences(const gkmhip_ctx *ctx) { return ctx ? ctx->n : 0; }
+extern "C" int gkmhip_device_of(const gkmhip_ctx *ctx) { return ctx ? ctx->device : -1; }
 
 extern "C" int gkmhip_set_scratch_slot(gkmhip_ctx *ctx, int slot)
 {
@@ -767,7 +785,12 @@ static bs_kernel_t pick_bitslice(int L, int d)
 {
 #define GKM_BS(LL, DD) \
     if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
-    if (L == 11 && d == 3) { /* timing experiments (tools/variants.sh); results are wrong for != 0 */
+#ifdef GKM_TIMING_VARIANTS
+    /* Ablation builds only (tools/variants.sh compiles them into build_variants/ with
+     * -DGKM_TIMING_VARIANTS): VARIANT != 0 skips parts of the kernel, the results are WRONG.  The
+     * product library is built without the macro: no such instantiation, no environment switch
+     * (tests/test_host_logic.py::test_no_timing_variants_in_the_product). */
+    if (L == 11 && d == 3) {
         const char *v = getenv("GKM_VARIANT");
         const int vi = v ? atoi(v) : 0;
         if (vi == 1) return k_gram_bitslice<W, 11, 3, PACKED, 1>;
@@ -775,6 +798,7 @@ static bs_kernel_t pick_bitslice(int L, int d)
         if (vi == 16) return k_gram_bitslice<W, 11, 3, PACKED, 16>;
         if (vi == 32) return k_gram_bitslice<W, 11, 3, PACKED, 32>;
     }
+#endif
     /* every (L, d) the parameter check admits (3 <= L <= 12, d <= min(4, L - 1)), plus (12, 6) for the
      * device layer's own tests */
 #define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
@@ -1013,6 +1037,47 @@ extern "C" int gkmhip_normalize(gkmhip_ctx *ctx, double *G, int64_t ld, double *
         sq = ctx->sq.p;
     }
     return normalize_rows(ctx, G, ld, 0, ctx->n, sq, symmetric, stream);
+}
+
+/* The same from row slabs (multi-GPU assembly, gkm_multi.hip): matrix row a is row slot[a] of `src`
+ * (leading dimension lds); un-permutation and normalisation in one pass */
+__global__ void k_assemble_sqnorm(const double *__restrict__ src, int64_t lds, const int64_t *__restrict__ slot, int n,
+                                  double *__restrict__ sq)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) sq[i] = sqrt(src[slot[i] * lds + i]); /* libgkm.c:753-758 */
+}
+
+__global__ void k_assemble_normalize(const double *__restrict__ src, int64_t lds, const int64_t *__restrict__ slot,
+                                     double *__restrict__ K, int64_t ld, const double *__restrict__ sq, int rbf,
+                                     double gamma, int symmetric)
+{
+    const int a = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > a) return;
+    double v = 1.0;
+    if (j != a) {
+        v = src[slot[a] * lds + j] / (sq[a] * sq[j]); /* libgkm.c:1169-1172 */
+        if (rbf) v = exp(gamma * (v - 1));
+        if (symmetric) K[(int64_t)j * ld + a] = v;
+    }
+    K[(int64_t)a * ld + j] = v;
+}
+
+extern "C" int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds, const int64_t *slot_of_row,
+                                         double *K, int64_t ld, double *sqnorm, int symmetric, void *stream_)
+{
+    if (!ctx || !slabs || !slot_of_row || !K || !sqnorm || ctx->n <= 0 || ld < ctx->n || lds < ctx->n)
+        return set_err_msg("gkmhip_assemble_normalize: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int n = ctx->n;
+    hipLaunchKernelGGL(k_assemble_sqnorm, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, slabs, lds, slot_of_row, n, sqnorm);
+    HIPCHK(hipGetLastError());
+    hipLaunchKernelGGL(k_assemble_normalize, dim3((unsigned)((n + 255) / 256), (unsigned)n), dim3(256), 0, stream, slabs, lds,
+                       slot_of_row, K, ld, sqnorm, ctx->rbf, ctx->gamma, symmetric);
+    HIPCHK(hipGetLastError());
+    return 0;
 }
 
 /* Whole matrix into caller-owned host rows (rows[a][0..a]) as a pipeline over row blocks of

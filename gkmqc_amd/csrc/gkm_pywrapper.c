@@ -65,6 +65,7 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     gkmhip_ctx *ctx = NULL;
     double *dG = NULL;
     uint8_t *wd = NULL;
+    int caller_device = -1;
     const double t_start = now_ms();
 
     if (!opts || !kmat || !kmat_size) return 1;
@@ -105,8 +106,11 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         return 1;
     }
 
-    double c[GKM_MAX_L + 1];
-    gkm_mismatch_weights(kt, L, k, c);
+    double c[GKM_MAX_L + 1] = {0};
+    if (gkm_mismatch_weights(kt, L, k, c)) { /* e.g. k < 0, which the reference's check lets through */
+        gkm_log(GKM_LOG_ERROR, "k should be in the range 0..L");
+        return 1;
+    }
     gkm_log(GKM_LOG_DEBUG, "gkm-kernel weights:");
     for (int m = 0; m <= d; m++) gkm_log(GKM_LOG_DEBUG, "  c[%d] = %.6f", m, c[m]);
 
@@ -162,22 +166,40 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         const char *list = getenv("GKM_DEVICES");
         const char *one = getenv("GKM_DEVICE");
         const int avail = gkmhip_device_count();
+        int bad_list = 0;
         if (list && *list) {
             if (!strcmp(list, "all")) {
                 for (int i = 0; i < avail && ndev < GKM_MAX_DEVICES; i++) devs[ndev++] = i;
             } else if (strchr(list, ',')) {
-                for (const char *q = list; *q && ndev < GKM_MAX_DEVICES;) {
-                    devs[ndev++] = atoi(q);
-                    q = strchr(q, ',');
-                    if (!q) break;
-                    q++;
+                for (const char *q = list; ndev < GKM_MAX_DEVICES;) {
+                    char *end = NULL;
+                    const long v = strtol(q, &end, 10);
+                    if (end == q || (*end && *end != ',') || v < 0 || v >= avail) { bad_list = 1; break; }
+                    devs[ndev++] = (int)v;
+                    if (!*end) break;
+                    q = end + 1;
                 }
             } else {
-                for (int i = 0; i < atoi(list) && ndev < GKM_MAX_DEVICES; i++) devs[ndev++] = i;
+                char *end = NULL;
+                const long v = strtol(list, &end, 10);
+                if (end == list || *end || v < 1 || v > avail) bad_list = 1;
+                for (int i = 0; !bad_list && i < (int)v && ndev < GKM_MAX_DEVICES; i++) devs[ndev++] = i;
             }
+        } else if (one && *one) {
+            char *end = NULL;
+            const long v = strtol(one, &end, 10);
+            if (end == one || *end || v < 0 || v >= (avail > 0 ? avail : 1)) bad_list = 1;
+            else devs[ndev++] = (int)v;
         }
-        if (ndev == 0) devs[ndev++] = one ? atoi(one) : 0;
+        if (bad_list) {
+            gkm_log(GKM_LOG_ERROR, "GKM_DEVICES / GKM_DEVICE must name HIP devices 0..%d (\"all\", a count, or a comma-separated list)",
+                    avail - 1);
+            goto done;
+        }
+        if (ndev == 0) devs[ndev++] = 0;
     }
+    /* the call must not change the caller's current HIP device (it may be a torch process) */
+    caller_device = gkmhip_current_device();
     double t_created = t_parsed, t_uploaded = t_parsed, t_alloc = t_parsed;
     if (ndev == 1) {
         const int device = devs[0];
@@ -240,6 +262,7 @@ done:;
     const double t_done = now_ms();
     if (dG) gkmhip_free(dG);
     if (ctx) gkmhip_destroy(ctx);
+    if (caller_device >= 0) gkmhip_set_current_device(caller_device);
     free(wd);
     gkm_problem_free(prob);
     gkm_log(GKM_LOG_DEBUG, "timing: teardown %.1f ms, whole call %.1f ms", now_ms() - t_done, now_ms() - t_start);

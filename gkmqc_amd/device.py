@@ -126,6 +126,19 @@ def load():
     L.gkmhip_gram_part_to_host_rows.restype = i32
     L.gkmhip_gram_part_to_host_rows.argtypes = (vp, vp, i64, vp, i32, i32, i32)
     L.gkmhip_release_host_cache.restype = None
+    L.gkmhip_current_device.restype = i32
+    L.gkmhip_set_current_device.restype = i32
+    L.gkmhip_set_current_device.argtypes = (i32,)
+    L.gkmhip_n_sequences.restype = i32
+    L.gkmhip_n_sequences.argtypes = (vp,)
+    L.gkmhip_device_of.restype = i32
+    L.gkmhip_device_of.argtypes = (vp,)
+    L.gkmhip_gram_allgather.restype = i32
+    L.gkmhip_gram_allgather.argtypes = (vp, i32, vp, i64, i32, i32)
+    L.gkmhip_last_transport.restype = ctypes.c_char_p
+    L.gkmhip_release_comms.restype = None
+    L.gkmhip_assemble_normalize.restype = i32
+    L.gkmhip_assemble_normalize.argtypes = (vp, vp, i64, vp, vp, i64, vp, i32, vp)
     L.gkmhip_last_kernel_ms.restype = dbl
     L.gkmhip_last_kernel_ms.argtypes = (vp,)
     L.gkmhip_last_comparisons.restype = dbl
@@ -300,6 +313,11 @@ class GramContext:
         self._chk(self.lib.gkmhip_normalize(self.handle, G_ptr, ld, sq_ptr, int(symmetric), stream),
                   "gkmhip_normalize")
 
+    def assemble_normalize(self, slabs_ptr, lds, slot_ptr, K_ptr, ld, sq_ptr, symmetric=False, stream=0):
+        """Un-permute (matrix row a = row slot[a] of the gathered slabs) + normalise in one pass."""
+        self._chk(self.lib.gkmhip_assemble_normalize(self.handle, slabs_ptr, lds, slot_ptr, K_ptr, ld, sq_ptr,
+                                                     int(symmetric), stream), "gkmhip_assemble_normalize")
+
     def last_kernel_ms(self):
         return self.lib.gkmhip_last_kernel_ms(self.handle)
 
@@ -359,3 +377,41 @@ def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, w
                         comparisons=ctx.last_comparisons())
     finally:
         ctx.close()
+
+
+def gram_matrix_multi(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devices=(0,), symmetric=False, chunks=0,
+                      kernel=KERNEL_AUTO):
+    """Whole Gram matrix computed on several GPUs by ONE process (include/gkm_hip.h,
+    gkmhip_gram_allgather): rows sharded by folded row blocks, slabs all-gathered over xGMI (RCCL),
+    every device ends up with the whole normalised matrix -- bit-identical to gram_matrix().
+    `devices` may name a device more than once (rehearsal on a one-GPU box: peer copies instead of RCCL).
+
+    Returns dict(K=[torch fp64 [n,n] per entry of devices], transport="rccl"|"p2p"|"none", ms=wall)."""
+    import time
+    import torch
+    lib = load()
+    ctxs = []
+    try:
+        for dv in devices:
+            c = GramContext(kernel_type, L, k, d, M, H, gamma, dv)
+            c.set_kernel(kernel)
+            ctxs.append(c)
+        n = len(seqs)
+        Ks = []
+        for c, dv in zip(ctxs, devices):
+            with torch.cuda.device(dv):
+                c.set_sequences(seqs, torch.cuda.current_stream().cuda_stream)
+                Ks.append(torch.zeros((n, n), dtype=torch.float64, device=torch.device("cuda", dv)))
+        for dv in set(devices):
+            torch.cuda.synchronize(dv)
+        handles = (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
+        outs = (ctypes.c_void_p * len(ctxs))(*[K.data_ptr() for K in Ks])
+        t0 = time.perf_counter()
+        rc = lib.gkmhip_gram_allgather(handles, len(ctxs), outs, n, int(symmetric), int(chunks))
+        wall = time.perf_counter() - t0
+        if rc:
+            raise GkmError("gkmhip_gram_allgather failed (%d): %s" % (rc, lib.gkmhip_last_error().decode()))
+        return dict(K=Ks, transport=lib.gkmhip_last_transport().decode(), ms=wall * 1e3)
+    finally:
+        for c in ctxs:
+            c.close()

@@ -42,11 +42,19 @@ enum { GKMHIP_KERNEL_AUTO = 0, GKMHIP_KERNEL_DIRECT = 1, GKMHIP_KERNEL_BITSLICE 
 
 const char *gkmhip_last_error(void);
 int gkmhip_device_count(void);
+/* the calling thread's current HIP device (-1 if there is none) / make `device` current: the
+ * boundary call restores the caller's device before it returns */
+int gkmhip_current_device(void);
+int gkmhip_set_current_device(int device);
 
 /* c: the d+1 mismatch weights c_0..c_d (host-computed, include/gkmkern_pylib.h).
  * rbf != 0 selects K <- exp(gamma (K-1)) in gkmhip_normalize (kernel types 3, 5). */
 gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, double gamma);
 void gkmhip_destroy(gkmhip_ctx *ctx);
+
+int gkmhip_n_sequences(const gkmhip_ctx *ctx); /* sequences uploaded */
+int gkmhip_device_of(const gkmhip_ctx *ctx);
+void gkmhip_set_error_message(const char *msg); /* what gkmhip_last_error() returns next (calling thread) */
 
 /* choose the kernel family (default AUTO: bit-sliced where supported) */
 /* Per-launch scratch (row tables of one gkmhip_gram_rows* call) exists twice.  A caller that issues
@@ -120,6 +128,30 @@ int gkmhip_gram_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **ro
  * This is how gkm_main_pywrapper uses several GPUs of a node (GKM_DEVICES). */
 int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double **rows, int nthreads, int part,
                                   int nparts);
+
+/* ---- several GPUs, one host process (gkm_multi.hip) ----
+ * Every context (one per device, same parameters, same sequences uploaded) computes the rows of its
+ * folded row blocks; the row slabs are all-gathered over xGMI (RCCL ncclAllGather on communicators
+ * made by ncclCommInitAll; peer copies when several contexts share one device or RCCL cannot be
+ * loaded; GKM_ALLGATHER=rccl|p2p forces one), then every device un-permutes and normalises its copy.
+ * K[g]: device pointer ON ctxs[g]'s DEVICE to an n x ld matrix that receives K (lower triangle +
+ * unit diagonal, the upper triangle too if symmetric != 0) -- the same matrix, bit for bit, as
+ * gkmhip_gram_rows + gkmhip_normalize produce on one device.  chunks: slabs per rank whose transfer
+ * overlaps the next slab's kernel (0 = default 4).  One host thread per device for the duration of
+ * the call; blocks until every device holds the matrix.  This is what feeds the GPU-resident
+ * cross-validation (include/gkm_svm.h) from an N-GPU matrix; the reference's consumer is
+ * scripts/gkmsvm.py:104-122. */
+int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, int64_t ld, int symmetric, int chunks);
+/* "rccl", "p2p" or "none": how the most recent gkmhip_gram_allgather moved the slabs */
+const char *gkmhip_last_transport(void);
+/* RCCL communicators are kept for the life of the process; this destroys them (optional) */
+void gkmhip_release_comms(void);
+
+/* Un-permutation + normalisation in one pass: matrix row a is row slot_of_row[a] (device array, n
+ * int64) of `slabs` (device, leading dimension lds, raw values); K receives what gkmhip_normalize
+ * would produce, sqnorm (device, n doubles) the self norms. */
+int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds, const int64_t *slot_of_row,
+                              double *K, int64_t ld, double *sqnorm, int symmetric, void *stream);
 
 /* The pinned staging buffers of the copy-out calls (2 x 64 MB) are kept for the life of the
  * process; this releases them (optional). */

@@ -110,7 +110,12 @@ def ref_K(opt, n):
 # name: n_pos, n_neg, length, length range, kernel type, L, k, d  (BASELINE.json configs[1], [2], [4])
 FULL_CONFIGS = {"c2": (5000, 5000, 300, None, 4, 11, 7, 3),
                 "c3": (10000, 10000, 300, None, 4, 11, 7, 3),
-                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4)}
+                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4),
+                # configs[3] stand-in: ONE `gkmqc.py evaluate` subset at its real size and parameters
+                # (reference bin/gkmqc.py:150-154,181-185: 5 000 peaks + 5 000 nulls x 600 bp, wgkm L=10 k=6 d=3)
+                # on the peak-like generator gkmqc_amd.synth.make_peak_sequences (no genome here)
+                "c4": (5000, 5000, 600, None, 4, 10, 6, 3)}
+PEAK_CONFIGS = ("c4",)
 
 
 def main():
@@ -119,6 +124,7 @@ def main():
     ap.add_argument("--full", action="append", choices=sorted(FULL_CONFIGS),
                     help="full-size digest of a BASELINE configuration through the reference (minutes to an hour)")
     ap.add_argument("--only-full", action="store_true", help="skip the small fixtures")
+    ap.add_argument("--threads", type=int, default=os.cpu_count(), help="row threads of the reference for --full")
     args = ap.parse_args()
     if not O.have_ref():
         raise SystemExit("oracle/_ref is not built: run `make -C oracle ref` where /root/reference exists")
@@ -181,8 +187,11 @@ def main():
         import time
         npos, nneg, ln, lr, t, L, k, d = FULL_CONFIGS[name]
         pf, nf = os.path.join(tmp, name + "_p.fa"), os.path.join(tmp, name + "_n.fa")
-        synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
-        opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=os.cpu_count())
+        if name in PEAK_CONFIGS:
+            synth.write_peak_problem(pf, nf, npos, nneg, ln)
+        else:
+            synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
+        opt = O.make_opt(t, L, k, d, 50, 50.0, 1.0, pf, nf, nthreads=args.threads)
         t0 = time.time()
         K, _ = ref_K(opt, npos + nneg)
         wall = time.time() - t0
@@ -193,9 +202,9 @@ def main():
                             sha256=np.frombuffer(hashlib.sha256(tri.tobytes()).digest(), dtype=np.uint8),
                             sample_idx=sel, sample_val=tri[sel],
                             row_sums=np.tril(K, -1).sum(axis=1), total=np.array(tri.sum()),
-                            ref_wall_s=np.array(wall), ref_threads=np.array(os.cpu_count()),
+                            ref_wall_s=np.array(wall), ref_threads=np.array(args.threads),
                             cfg=np.array([npos, nneg, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0, t, L, k, d]))
-        print("%s full: reference wall %.1f s on %d threads" % (name, wall, os.cpu_count()), flush=True)
+        print("%s full: reference wall %.1f s on %d threads" % (name, wall, args.threads), flush=True)
         del K, tri
 
 

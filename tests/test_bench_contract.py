@@ -1,5 +1,6 @@
 """bench.py's output contract: exactly one JSON line on stdout (libraries that write to file
-descriptor 1, like RCCL's version banner, must not leak into it) with the fields the driver reads."""
+descriptor 1, like RCCL's version banner, must not leak into it) with the fields the driver reads;
+`python bench.py --gpus N` must start its own ranks."""
 import json
 import os
 import subprocess
@@ -8,29 +9,98 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "1", "--n-pos", "400", "--n-neg", "400", "--cpu-sample", "150"]
+
+
+def _run(extra, env=None, timeout=900):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, cwd=ROOT, env=e,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    return r
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("forced_dist", [False, True])
-def test_one_json_line_with_roofline_and_cpu_baseline(built, forced_dist):
-    env = dict(os.environ)
-    if forced_dist:                      # the sharded path through the real RCCL backend, one rank
-        env["GKM_BENCH_FORCE_DIST"] = "1"
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "1", "--n-pos", "400",
-           "--n-neg", "400", "--cpu-sample", "150"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
-    assert r.returncode == 0
-    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+def test_one_json_line_with_roofline_end_to_end_and_cpu_baseline(built, forced_dist):
+    env = {"GKM_BENCH_FORCE_DIST": "1"} if forced_dist else {}   # the sharded path through real RCCL, one rank
+    d = _one_line(_run(SMALL, env))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "end_to_end"):
         assert key in d, key
     assert d["unit"] == "pairs/s" and d["n_gpus"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
     rf = d["roofline"]
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_Gops", "pmc_source"):
         assert key in rf, key
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["kernel_ms"] > 0
+    # a custom problem size has no PMC summary: the executed-instruction figures must be null, never stale
+    assert rf["frac"] is None and rf["achieved"] is None and rf["kernel_ms"] > 0
+    assert rf["algorithmic_frac"] == pytest.approx(rf["algorithmic_Gops"] / rf["peak"])
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    e2e = d["end_to_end"]
+    assert e2e["boundary_ms"] > 0 and e2e["pipeline_ms"] > 0 and 0.0 <= e2e["pipeline_auc"] <= 1.0
     assert "workload" in d["config"] and "model" not in d["config"]
+    if forced_dist:
+        assert d["config"]["env"].get("GKM_BENCH_FORCE_DIST") == "1"   # GKM_* knobs are on record
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("assembly", ["torch", "cabi"])
+def test_plain_gpus_2_launches_its_own_ranks(built, assembly):
+    """No launcher, no WORLD_SIZE: `python bench.py --gpus 2` (two ranks sharing the box's one GPU; the
+    torch path then moves the slabs through gloo, the one-process C-ABI path by peer copies) prints one
+    line with n_gpus 2, and --check holds the assembled matrix to the single-GPU one bit for bit."""
+    env = {"GKM_BENCH_SHARE_GPU": "1", "GKM_BENCH_BACKEND": "gloo"}
+    d = _one_line(_run(["--gpus", "2", "--assembly", assembly, "--check", "--no-cpu-baseline"] + SMALL, env))
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] is None
+    assert "end_to_end" not in d and "cpu_baseline" not in d
+
+
+def test_headline_roofline_uses_only_a_matching_pmc_summary(tmp_path, monkeypatch):
+    """frac comes from rocprofv3 SQ_INSTS_VALU of the committed summary; a summary taken on other kernel
+    code (hash mismatch) or another workload must be refused."""
+    sys.path.insert(0, ROOT)
+    import bench
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    for rel in bench.KERNEL_SOURCES:
+        os.makedirs((tmp_path / rel).parent, exist_ok=True)
+        (tmp_path / rel).write_text("v1 " + rel)
+    good = bench.kernel_source_hash()
+    (tmp_path / "profiles" / "r2_pmc_c2.json").write_text(json.dumps(
+        {"workload": "c2", "kernel_source_sha256": good, "per_launch": {"SQ_INSTS_VALU": 1.0}}))
+    d, src = bench.pmc_summary("c2")
+    assert d is not None and src == "r2_pmc_c2.json"
+    assert bench.pmc_summary("peaks")[0] is None
+    (tmp_path / bench.KERNEL_SOURCES[0]).write_text("v2: the kernel changed")
+    d, why = bench.pmc_summary("c2")
+    assert d is None and "stale" in why
+
+
+def test_workload_table_matches_baseline_configs():
+    sys.path.insert(0, ROOT)
+    import bench
+    a = bench.parse_args([])
+    assert (a.n_pos, a.n_neg, a.length, a.kernel_type, a.L, a.k, a.d, a.custom) == (5000, 5000, 300, 4, 11, 7, 3, False)
+    assert a.label == "configs[1]"
+    p = bench.parse_args(["--workload", "peaks"])     # reference bin/gkmqc.py:150-154,181-185
+    assert (p.n_pos, p.n_neg, p.length, p.L, p.k, p.d, p.generator) == (5000, 5000, 600, 10, 6, 3, "peaks")
+    assert bench.parse_args(["--n-pos", "400"]).custom
+
+
+def test_plain_gpus_n_without_gpus_fails_cleanly():
+    """The parent must spawn, wait for and report its ranks -- here they all fail (no GPU) -- not hang
+    and not claim success."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without GPUs")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n-pos", "20", "--n-neg", "20"], timeout=300)
+    assert r.returncode != 0 and r.stdout.decode().strip() == ""

@@ -352,3 +352,38 @@ def test_boundary_over_several_device_contexts(dev, monkeypatch, devices):
     assert (one == many).all()
     assert (np.triu(many, 1) == 0).all() and (np.diag(many) == 1.0).all()
     assert helpers.max_rel_err(helpers.tril_pack(many), z["c2_cut192_K"]) < K_TOL
+
+
+@pytest.mark.parametrize("nctx,chunks", [(2, 0), (3, 2), (5, 4)])
+def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
+    """gkmhip_gram_allgather (include/gkm_hip.h): several contexts -- here all on the one GPU of the
+    box, so the slabs move by peer copies -- must assemble the same matrix, bit for bit, as one
+    context alone; every context's copy is checked, ragged lengths and the tiny quirks problem
+    (fewer rows than 2 x ranks x 64) included."""
+    import torch
+    seqs, _ = quirk_seqs
+    big = helpers.synth_codes(300, 300, 300, (150, 400))
+    for problem, (t, L, k, d) in ((seqs, (4, 11, 7, 3)), (big, (5, 10, 6, 3))):
+        one = dev.gram_matrix(problem, t, L, k, d, gamma=2.0, symmetric=True)["K"]
+        res = dev.gram_matrix_multi(problem, t, L, k, d, gamma=2.0, devices=[0] * nctx, symmetric=True, chunks=chunks)
+        assert res["transport"] == "p2p"
+        for K in res["K"]:
+            assert torch.equal(K, one), "assembled matrix differs from the single-GPU matrix"
+        low = dev.gram_matrix_multi(problem, t, L, k, d, gamma=2.0, devices=[0] * nctx, symmetric=False, chunks=chunks)
+        assert torch.equal(low["K"][nctx - 1], torch.tril(one))
+
+
+def test_one_process_assembly_through_rccl(dev, monkeypatch):
+    """The RCCL binding itself (dlopen, ncclCommInitAll, ncclAllGather on the transfer stream) on the
+    one device a test box has: a one-rank communicator; more ranks need more GPUs (the driver's node)."""
+    import torch
+    monkeypatch.setenv("GKM_ALLGATHER", "rccl")
+    problem = helpers.synth_codes(150, 150, 300)
+    one = dev.gram_matrix(problem, 4, 11, 7, 3)["K"]
+    for _ in range(2):   # second call: cached communicator
+        res = dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0])
+        assert res["transport"] == "rccl"
+        assert torch.equal(res["K"][0], one)
+    with pytest.raises(dev.GkmError):   # RCCL refuses one device twice; the call must fail cleanly, not hang
+        dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0, 0])
+    dev.load().gkmhip_release_comms()

@@ -53,6 +53,27 @@ def test_chunked_layout_properties():
                 assert pc <= -(-sharding.slab_rows(n, world) // chunks) + sharding.CHUNK_GROUP, "little padding"
 
 
+def test_cpp_layout_matches_python(built):
+    """gkm_shard.h (used by the one-process multi-GPU entry gkmhip_gram_allgather) against
+    gkmqc_amd/sharding.py (used by bench.py's one-process-per-GPU path)."""
+    import ctypes
+    from gkmqc_amd import sharding
+    lib = ctypes.CDLL(os.path.join(helpers.ROOT, "gkmqc_amd", "csrc", "bitslice_cpu_probe.so"))
+    for n in (1, 5, 63, 64, 65, 400, 1000, 10001):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4, 5):
+                slot = np.zeros(n, dtype=np.int64)
+                lib.shardprobe_gather_index(n, world, chunks, slot.ctypes.data_as(ctypes.c_void_p))
+                assert (slot == sharding.chunked_gather_index(n, world, chunks)).all()
+                for rank in range(world):
+                    parts, pc = sharding.chunked_layout(n, world, rank, chunks)
+                    assert lib.shardprobe_chunk_rows(n, world, chunks) == pc
+                    for c in range(chunks):
+                        buf = np.zeros(pc + 1, dtype=np.int32)
+                        cnt = lib.shardprobe_part(n, world, rank, chunks, c, buf.ctypes.data_as(ctypes.c_void_p))
+                        assert cnt == len(parts[c]) and (buf[:cnt] == parts[c]).all()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
