@@ -47,6 +47,8 @@ WORKLOADS = {
     # configs[3] stand-in: ONE subset of `gkmqc.py evaluate` at its real size and parameters (reference
     # bin/gkmqc.py:150-154,181-185) on peak-like synthetic sequences (gkmqc_amd/synth.py); the genome is not here
     "peaks": (5000, 5000, 600, None, 4, 10, 6, 3, "peaks", "configs[3] stand-in (one evaluate subset)"),
+    # the same size and parameters on iid ACGT: what the peak-like composition costs is peaks vs d600
+    "d600": (5000, 5000, 600, None, 4, 10, 6, 3, "iid", "gkmQC's default parameters on iid sequences"),
 }
 
 

@@ -29,12 +29,13 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
             for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
         }
     const uint32_t rcpT = mod_magic((uint32_t)T);
-    auto weight = [&](int n, int p) { return wd ? (uint32_t)wd[n / 2 > p ? n / 2 - p : p - n / 2] : 1u; };
-    std::vector<uint32_t> lmA((size_t)nA), lmB[2];
-    for (int p = 0; p < nA; p++) lmA[(size_t)p] = lmer_entry(A, lenA, L, 0, p, weight(nA, p));
+    auto wdist = [&](int dd) { return wd ? (uint32_t)wd[dd] : 1u; };
+    /* packed column strands, as the kernel holds them in LDS */
+    const int pkw = (T + 15) / 16 + 1;
+    std::vector<uint32_t> pkB[2];
     for (int st = 0; st < 2; st++) {
-        lmB[st].resize((size_t)nB);
-        for (int q = 0; q < nB; q++) lmB[st][(size_t)q] = lmer_entry(B, lenB, L, st, q, weight(nB, st ? nB - 1 - q : q));
+        pkB[st].resize((size_t)pkw);
+        for (int x = 0; x < pkw; x++) pkB[st][(size_t)x] = pk_word(B, T, st, x);
     }
     for (int s0 = 0; s0 < nA; s0 += CAP) {
         uint32_t Ahi[W], Alo[W], AV[W];
@@ -43,8 +44,19 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
             Alo[w] = row_plane_word(A, lenA, s0, w, W, L, 1);
             AV[w] = row_plane_word(A, lenA, s0, w, W, L, 2);
         }
-        auto rl = [&](int i0) { return lmA[(size_t)(s0 + i0)]; };
-        auto cl = [&](int st, int q) { return lmB[st][(size_t)q]; };
+        /* the lane's packed positions: base i of the segment is sequence position s0 + i */
+        uint32_t lanepk[2 * W + 2];
+        for (int x = 0; x < 2 * W + 2; x++) {
+            uint32_t v = 0u;
+            for (int k = 0; k < 16; k++) {
+                const int pos = s0 + x * 16 + k;
+                if (x * 16 + k < 32 * W && pos < lenA) v |= (uint32_t)A[pos] << (2 * k);
+            }
+            lanepk[x] = v;
+        }
+        auto rl = [&](int i0) { return pk_window(lanepk[i0 >> 4], lanepk[(i0 >> 4) + 1], i0); };
+        auto cl = [&](int st, int q) { return pk_window(pkB[st][(size_t)(q >> 4)], pkB[st][(size_t)(q >> 4) + 1], q); };
+        const int c0 = nA / 2 - s0;
         for (int st = 0; st < 2; st++)
             for (int delta = 0; delta < T; delta++) {
                 uint32_t hit[W];
@@ -56,8 +68,8 @@ static void run_pair(const uint8_t *A, int lenA, const uint8_t *B, int lenB, con
                     while (h) {
                         const int bit = __builtin_ctz(h);
                         h &= h - 1u;
-                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, rl, cl);
-                        acc[hv.m] += hv.v;
+                        const HitValue hv = resolve_hit_packed<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, L, c0, rl, cl, wdist);
+                        if (hv.m <= D) acc[hv.m] += hv.v; /* (a wrapped window comes back as m = 0, v = 0) */
                     }
                 }
             }
@@ -133,11 +145,12 @@ static int run_packed(const uint8_t *codes, const int64_t *off, const int *rows,
             sb[st][pl].resize((size_t)T + W);
             for (int x = 0; x < T + W; x++) sb[st][pl][(size_t)x] = sb_word(B, T, st, x, W, L, pl);
         }
-    auto weight = [&](int n, int p) { return wd ? (uint32_t)wd[n / 2 > p ? n / 2 - p : p - n / 2] : 1u; };
-    std::vector<uint32_t> lmB[2];
+    auto wdist = [&](int Dd) { return wd ? (uint32_t)wd[Dd] : 1u; };
+    const int pkw = (T + 15) / 16 + 1;
+    std::vector<uint32_t> pkB[2];
     for (int st = 0; st < 2; st++) {
-        lmB[st].resize((size_t)nB);
-        for (int q = 0; q < nB; q++) lmB[st][(size_t)q] = lmer_entry(B, T, L, st, q, weight(nB, st ? nB - 1 - q : q));
+        pkB[st].resize((size_t)pkw);
+        for (int x = 0; x < pkw; x++) pkB[st][(size_t)x] = pk_word(B, T, st, x);
     }
     const uint32_t rcpT = mod_magic((uint32_t)T);
     std::vector<uint32_t> acc((size_t)nrows * (D + 1), 0u);
@@ -146,7 +159,9 @@ static int run_packed(const uint8_t *codes, const int64_t *off, const int *rows,
         size_t pj = pi;
         while (pj < P.pieces.size() && P.pieces[pj].lane == P.pieces[pi].lane) pj++;
         uint32_t Ahi[W], Alo[W], AV[W], start_mask = 0u;
+        uint32_t lanepk[2 * W + 2]; /* the lane's packed positions (what k_build_rowplanes writes as plane 3) */
         for (int w = 0; w < W; w++) Ahi[w] = Alo[w] = AV[w] = 0u;
+        for (int x = 0; x < 2 * W + 2; x++) lanepk[x] = 0u;
         for (size_t k = pi; k < pj; k++) {
             const Piece &pc = P.pieces[k];
             start_mask |= 1u << pc.b0;
@@ -157,6 +172,9 @@ static int run_packed(const uint8_t *codes, const int64_t *off, const int *rows,
                     Ahi[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 0) << b;
                     Alo[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 1) << b;
                     AV[w] |= piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 2) << b;
+                    const int i = b * W + w;
+                    lanepk[i >> 4] |= ((piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 0) << 1) |
+                                       piece_bit(seq, len, pc.b0, pc.nb, pc.p0, pc.cnt, b, w, W, 1)) << (2 * (i & 15));
                 }
         }
         for (int st = 0; st < 2; st++)
@@ -172,13 +190,13 @@ static int run_packed(const uint8_t *codes, const int64_t *off, const int *rows,
                         const Piece &pc = P.pieces[pi + (size_t)piece_of_bitrow(start_mask, bit)];
                         const uint8_t *seq = codes + off[pc.row];
                         const int len = (int)(off[pc.row + 1] - off[pc.row]), nA = len - L + 1;
-                        /* the device reads lmf[lmbase + i0] with lmbase = lmoff[row] + p0 - b0*W */
-                        auto rl = [&](int i0) {
-                            const int p = pc.p0 + i0 - pc.b0 * W;
-                            return lmer_entry(seq, len, L, 0, p, weight(nA, p));
-                        };
-                        auto cl = [&](int s2, int q) { return lmB[s2][(size_t)q]; };
-                        const HitValue hv = resolve_hit<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, rl, cl);
+                        /* the device keeps c0 = nA/2 - p0 + b0*W per piece: the row l-mer of lane position i0 is
+                         * l-mer p = p0 + i0 - b0*W of its sequence, |c0 - i0| away from the centre l-mer */
+                        auto rl = [&](int i0) { return pk_window(lanepk[i0 >> 4], lanepk[(i0 >> 4) + 1], i0); };
+                        auto cl = [&](int s2, int q) { return pk_window(pkB[s2][(size_t)(q >> 4)], pkB[s2][(size_t)(q >> 4) + 1], q); };
+                        const int c0 = nA / 2 - pc.p0 + pc.b0 * W;
+                        (void)seq;
+                        const HitValue hv = resolve_hit_packed<W>(bit, w, delta, st, (uint32_t)T, rcpT, nB, L, c0, rl, cl, wdist);
                         const int i = P.tile_out[(size_t)(pc.lane / LANES) * MAX_ROWS + pc.slot];
                         if (hv.m <= D) acc[(size_t)i * (D + 1) + hv.m] += hv.v;
                         else if (hv.v != 0u) return -20; /* a true hit can never exceed D */

@@ -437,6 +437,72 @@ GKM_HD HitValue resolve_hit(int b, int w, int delta, int strand, uint32_t T, uin
     return r;
 }
 
+/* ---- 2-bit packed strands: what the hit path reads -------------------------------------------
+ * 16 bases per 32-bit word, base i of a strand in bits 2(i%16)..2(i%16)+1 of word i/16, zeros beyond
+ * the end.  The l-mer starting at base pos is the low 2L bits of the 64-bit value (word[pos/16 + 1] :
+ * word[pos/16]) >> 2(pos%16) -- one funnel shift (v_alignbit_b32) on two neighbouring words.  A hit
+ * gathers two words of the row lane's packed positions (64 lanes x 21 words per tile: a few cache
+ * lines, L1 resident) and two words of the column strand from LDS, instead of one 4-byte table entry
+ * per l-mer and side: the per-l-mer tables made every gather touch 64 different cache lines, and the
+ * vector memory pipeline, not the VALU, set the pace of the hit path (config 2: 18 of 91 ms). */
+GKM_HD uint32_t pk_word(const uint8_t *codes, int len, int strand, int x)
+{
+    uint32_t v = 0u;
+    for (int k = 0; k < 16; k++) {
+        const int i = x * 16 + k;
+        if (i >= len) break;
+        const uint32_t c = strand ? (3u - codes[len - 1 - i]) : codes[i];
+        v |= c << (2 * k);
+    }
+    return v;
+}
+GKM_HD uint32_t pk_window(uint32_t lo, uint32_t hi, int pos)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, (uint32_t)(2 * (pos & 15)));
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (2 * (pos & 15)));
+#endif
+}
+/* Hamming distance of the first L bases of two packed windows */
+GKM_HD int pk_mismatch(uint32_t a, uint32_t b, int L)
+{
+    uint32_t t = (a ^ b) & ((1u << (2 * L)) - 1u);
+    t = (t | (t >> 1)) & 0x55555555u;
+    return __builtin_popcount(t);
+}
+
+/* Resolve one hit from packed data: bit b of the hit word of (delta, w, strand) against a row lane.
+ *   lane position i0 = b*W + w; column l-mer q = (i0 + delta) mod T on `strand` (rejected if it wraps)
+ *   roww(i0)        32-bit packed window of the row LANE's positions starting at i0
+ *   colw(strand, q) 32-bit packed window of the column strand starting at base q
+ *   wdist(D)        positional weight at distance D from the centre l-mer (libgkm.c:912-925); 1 if unweighted
+ *   c0              (l-mers of the row)/2 - p0 + b0*W of the piece that owns the bit row, so that the
+ *                   row l-mer's distance to its sequence's centre l-mer is |c0 - i0|
+ * The reverse strand's weights are the forward ones mirrored: wt_rc[q] = wt[nB-1-q] (libgkm.c:924). */
+template <int W, class RowWin, class ColWin, class Wdist>
+GKM_HD HitValue resolve_hit_packed(int b, int w, int delta, int strand, uint32_t T, uint32_t rcpT, int nB, int L, int c0,
+                                   RowWin roww, ColWin colw, Wdist wdist)
+{
+    HitValue r;
+    r.m = 0;
+    r.v = 0u;
+    const int i0 = b * W + w;
+    const uint32_t x = (uint32_t)(i0 + delta);
+    int q;
+    if (T >= (uint32_t)(32 * W)) { /* x < 2T: one conditional subtraction (uniform test) */
+        const uint32_t y = x - T;
+        q = (int)(y < x ? y : x);
+    } else {
+        q = (int)mod_small(x, T, rcpT);
+    }
+    if (q >= nB) return r; /* window wraps around the end of the strand: not an l-mer (see window_hits) */
+    r.m = pk_mismatch(roww(i0), colw(strand, q), L);
+    const int da = c0 - i0, qd = strand ? nB - 1 - q : q, db = nB / 2 - qd;
+    r.v = wdist(da < 0 ? -da : da) * wdist(db < 0 ? -db : db);
+    return r;
+}
+
 /* hit record: w (6 bits) | delta << 6 (11) | strand << 17 | source lane << 18 (6) | bit << 24 (5) */
 GKM_HD uint32_t pack_meta(int delta, int w, int strand)
 {

@@ -152,19 +152,23 @@ struct gkmhip_ctx {
     int wd_len = 0;
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
-    DevBuf<uint32_t> lmf, sb; /* lmf: forward l-mer table, then the reverse-strand table */
+    DevBuf<uint32_t> lmf, sb; /* lmf: forward l-mer table, then the reverse-strand table (general kernel only) */
+    DevBuf<uint32_t> colpk;   /* 2-bit packed strands [seq][strand][pkw] (gkm_bitslice.h pk_word): the hit path's column side */
+    int pkw = 0;
+    bool have_colpk = false;
     uint32_t lm_stride = 0;
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
     /* per-call scratch, two sets (gkmhip_set_scratch_slot): a caller that alternates launches between
      * two streams alternates the slot, so a launch never rewrites what the previous one still reads */
     struct Scratch {
-        DevBuf<int> rows, piece_desc, tile_row, tile_out, tile_nrows, tile_cbeg, tile_cend;
-        DevBuf<uint32_t> rowplanes, lane_mask, lane_piece;
+        DevBuf<int> rows;
+        DevBuf<char> tables;       /* all per-launch tables of the bit-sliced kernel, one upload */
+        DevBuf<uint32_t> rowplanes, rowpk;
+        DevBuf<double> S;          /* tile-transposed raw values (k_gram_bitslice -> k_untile) */
         void release()
         {
-            rows.release(); piece_desc.release(); tile_row.release(); tile_out.release(); tile_nrows.release();
-            tile_cbeg.release(); tile_cend.release(); rowplanes.release(); lane_mask.release(); lane_piece.release();
+            rows.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
         }
     } scratch[2];
     int sel = 0;
@@ -212,7 +216,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
-    ctx->len.release(); ctx->lmf.release(); ctx->sb.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release();
     ctx->scratch[0].release(); ctx->scratch[1].release(); ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -258,6 +262,16 @@ __global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *_
     }
 }
 
+/* grid (sequence*2+strand); threads over the words of the strand's 2-bit packed copy (gkm_bitslice.h pk_word) */
+__global__ void k_pack_strands(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int pkw,
+                               uint32_t *__restrict__ colpk)
+{
+    const int e = blockIdx.x, s = e >> 1, strand = e & 1;
+    const uint8_t *seq = codes + off[s];
+    const int T = (int)(off[s + 1] - off[s]);
+    for (int x = threadIdx.x; x < pkw; x += blockDim.x) colpk[(size_t)e * pkw + x] = gkmbs::pk_word(seq, T, strand, x);
+}
+
 /* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
 __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
                            int L, int xw, uint32_t *__restrict__ sb)
@@ -272,12 +286,34 @@ __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__r
 }
 
 /* Packed lanes (gkm_pack.h): grid (tile, plane); 64 threads = the tile's lanes; output layout
- * [tile][plane][w][lane].  desc holds MAX_PIECES x {row, b0, nb, p0, cnt} per lane (nb = 0: unused). */
+ * [tile][plane][w][lane].  desc holds MAX_PIECES x {row, b0, nb, p0, cnt} per lane (nb = 0: unused).
+ * plane 3: the lane's positions 2-bit packed for the hit path, rowpk[(tile*64 + lane) * rpw + x]
+ * (16 positions per word, position i = bit row i / W, word i % W of the bit planes). */
 __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
-                                  const int *__restrict__ desc, int W, uint32_t *__restrict__ planes)
+                                  const int *__restrict__ desc, int W, uint32_t *__restrict__ planes,
+                                  uint32_t *__restrict__ rowpk, int rpw)
 {
     const int tile = blockIdx.x, plane = blockIdx.y, lane = threadIdx.x;
     const int *d = desc + (size_t)(tile * 64 + lane) * gkmpack::MAX_PIECES * 5;
+    if (plane == 3) {
+        for (int x = 0; x < rpw; x++) {
+            uint32_t v = 0u;
+            for (int k = 0; k < gkmpack::MAX_PIECES; k++) {
+                const int row = d[k * 5 + 0], b0 = d[k * 5 + 1], nb = d[k * 5 + 2], p0 = d[k * 5 + 3];
+                if (nb <= 0) continue;
+                const uint8_t *seq = codes + off[row];
+                const int len = (int)(off[row + 1] - off[row]);
+                for (int q = 0; q < 16; q++) {
+                    const int i = x * 16 + q, b = i / W;
+                    if (b < b0 || b >= b0 + nb) continue;
+                    const int pos = p0 + i - b0 * W;
+                    if (pos < len) v |= (uint32_t)seq[pos] << (2 * q);
+                }
+            }
+            rowpk[(size_t)(tile * 64 + lane) * rpw + x] = v;
+        }
+        return;
+    }
     for (int w = 0; w < W; w++) {
         uint32_t v = 0u;
         for (int k = 0; k < gkmpack::MAX_PIECES; k++) {
@@ -310,15 +346,28 @@ struct BsArgs {
     const uint32_t *lane_mask;  /* [tile*64] bit rows at which a piece starts */
     const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
     const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
-    const uint32_t *lmf, *lmr;  /* l-mer table entries (l-mer | weight << 24) per strand */
-    uint32_t lm_stride;         /* lmr == lmf + lm_stride */
-    const int64_t *lmoff;
+    const uint32_t *rowpk;      /* [tile*64 + lane][rpw] the lanes' positions, 2-bit packed (k_build_rowplanes) */
+    const uint32_t *colpk;      /* [seq*2 + strand][pkw] 2-bit packed strands                                 */
+    const uint32_t *wd32;       /* distance-indexed positional weights (bytes), wd_words dwords               */
+    int rpw, pkw, wd_words;
     const uint32_t *sb;
     int xw;
     const int *len;
     double c[GKM_MAXD1];
     GramOut out;
-    int cj;
+    /* Work items = (tile, column) pairs, one wavefront each, as a 1-D grid of exactly the pairs inside the
+     * visited region (the 2-D (column, tile) grid launched as many empty blocks as real ones): item =
+     * tile_soff[tile] + (j - cbeg[tile]), columns fastest.  Neighbouring blocks -- the waves resident on
+     * a CU at the same time -- therefore work on the SAME row tile (its packed rows stay in the CU's L1)
+     * and on DIFFERENT columns.  The opposite order (all tiles of a column next to each other on one XCD,
+     * so that the column tables come from that XCD's L2) was measured: 91 instead of 85 ms on config 2
+     * and 1000 instead of 509 ms on the peak-like set -- the waves of a CU then hit the same dense column
+     * regions at the same moment and all wait on the hit path together. */
+    int ntiles;
+    /* raw Gram values leave the kernel tile-transposed: S[(tile_soff[tile] + j - cbeg) * NSLOT + row slot],
+     * 64 consecutive doubles per store instruction; k_untile turns them into rows of G */
+    double *S;
+    const int64_t *tile_soff;
 };
 
 constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| + 1 for n <= 2047 */
@@ -338,6 +387,23 @@ __device__ __forceinline__ int wave_inclusive_scan(int x)
     return x;
 }
 
+/* position of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32's own convention; __builtin_ctz(0) is
+ * undefined and the generic cttz costs a second instruction) */
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* popcount(x) + acc in one instruction (hipcc sums separate popcounts with extra adds) */
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 #ifndef GKM_BS_GRP
 #define GKM_BS_GRP 5 /* config 2 / gkmQC's default L=10 k=6 d=3: 2 -> 89.8 / 118.1 ms, 5 -> 81.0 / 119.3, 10 -> 87.5 / 138.3 */
 #endif
@@ -345,8 +411,8 @@ constexpr int BS_GRP = GKM_BS_GRP;     /* hit words per list record: the lanes a
 #ifndef GKM_BS_TRIP
 #define GKM_BS_TRIP 64 /* config 2: 64 -> 87.2 ms (ring of 128: index wrap is one AND), 128 -> 89.1, 192 -> 97.3 */
 #endif
-constexpr int BS_TRIP = GKM_BS_TRIP; /* records resolved per trip (BS_TRIP / 64 per lane) */
-constexpr int BS_TK = BS_TRIP / 64;
+constexpr int BS_TRIP = GKM_BS_TRIP; /* records resolved per trip: one per lane */
+static_assert(BS_TRIP == 64, "a trip resolves one record per lane");
 /* records the wave-wide hit list (a ring) holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
 constexpr int BS_CAP = BS_TRIP + 64;
 constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
@@ -356,6 +422,9 @@ constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 #ifndef GKM_BS_WAVES
 #define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
                           config 2 with the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 */
+#endif
+#ifndef GKM_BS_PACKED_WAVES
+#define GKM_BS_PACKED_WAVES 1 /* several-pieces-per-lane kernel: no register cap asked (it takes ~90 VGPRs -> 5 waves) */
 #endif
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 
@@ -368,16 +437,20 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * control flow besides the push.
  */
 template <int W, int L, int D, bool PACKED, int VARIANT = 0>
-__global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
-    /* VARIANT (timing experiments only, selected by GKM_VARIANT; results are wrong for != 0):
-     * 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
-     * fetched with vector loads into VGPRs instead of scalar loads into SGPRs */
+    /* VARIANT (timing experiments only, -DGKM_TIMING_VARIANTS builds, selected by GKM_VARIANT; results are
+     * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
+     * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
+     * reads; 32 = records pushed, trips skipped; 64 = multi-hit records dropped after their first hit;
+     * 128 = trips without the LDS accumulate */
     using namespace gkmbs;
-    /* LDS per wave: 4 KB hit list + 1.25 KB accumulators + 0.25 KB -> 5.5 KB, so occupancy is set
-     * by registers.  The l-mer tables the hit resolution reads stay in global memory (1.2 KB per
-     * sequence and strand, L1/L2 resident): keeping LDS small buys the occupancy that hides the
-     * latency of the hit path (measured: 301 -> 244 ms on config 2 when the tables left LDS). */
+    /* LDS per wave: 3 KB hit ring + 0.5-2.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
+     * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
+     * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
+     * of the row lane's packed positions from global memory (5.4 KB per tile, L1 resident: the waves of a CU
+     * work on the same tile). */
+    extern __shared__ uint32_t s_dyn[]; /* [2 * pkw] column strands (forward, reverse complement), then wd_words */
     /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
      * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
      * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
@@ -392,7 +465,7 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
     constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
     constexpr int NSLOT = PACKED ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
     __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
-    __shared__ uint32_t lpiece[64 * NP * 2];     /* row slot, l-mer table base per piece       */
+    __shared__ uint32_t lpiece[64 * NP * 2];     /* row slot, centre offset c0 per piece       */
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
@@ -405,23 +478,17 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
     static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
-    /* blockIdx.x = column chunk, blockIdx.y = row tile.  The other order (tile fastest, so that the
-     * blocks sharing an XCD's L2 read the same column tables) was measured 2-3 % slower on config 2:
-     * the tables stream at ~100 GB/s only, the tail balance matters more. */
-    const int tile = blockIdx.y, chunk = blockIdx.x;
-    const int j0 = A.tile_cbeg[tile] + chunk * A.cj;
-    const int j1 = min(j0 + A.cj, A.tile_cend[tile]);
-    if (j0 >= j1) return;
-    const int nrows = A.tile_nrows[tile];
-    /* the row slots this lane finishes in the epilogue */
-    constexpr int NE = NSLOT / 64;
-    int my_row[NE], my_out[NE];
-#pragma unroll
-    for (int k = 0; k < NE; k++) {
-        const int rs = k * 64 + lane;
-        my_row[k] = rs < nrows ? A.tile_row[tile * gkmpack::MAX_ROWS + rs] : -1;
-        my_out[k] = rs < nrows ? A.tile_out[tile * gkmpack::MAX_ROWS + rs] : 0;
+    /* block -> (tile, column): see BsArgs.  All of this is wave-uniform (scalar loads, SALU). */
+    int lo = 0, hi = A.ntiles; /* largest tile with tile_soff[tile] <= blockIdx.x */
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (A.tile_soff[mid] <= (int64_t)blockIdx.x) lo = mid;
+        else hi = mid;
     }
+    const int tile = lo;
+    const int j0 = A.tile_cbeg[tile] + (int)((int64_t)blockIdx.x - A.tile_soff[tile]), j1 = j0 + 1;
+    const int nrows = A.tile_nrows[tile];
+    constexpr int NE = NSLOT / 64; /* row slots a lane finishes in the epilogue */
 
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
@@ -435,91 +502,92 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
 #pragma unroll
     for (int k = 0; k < NP * 2; k++) lpiece[lane * NP * 2 + k] = A.lane_piece[(size_t)(tile * 64 + lane) * NP * 2 + k];
     const uint32_t lane_tag = (uint32_t)lane << 18;
+    const int pkw = A.pkw;
+    uint32_t *const s_wd = s_dyn + 2 * pkw;
+    for (int x = lane; x < A.wd_words; x += 64) s_wd[x] = A.wd32[x];
+    /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
+     * base instead of a 64-bit address computed per lane) */
+    const char *const rowpk_tile = (const char *)(A.rowpk + (size_t)tile * 64 * A.rpw);
+    const uint32_t rpw4 = (uint32_t)A.rpw * 4u;
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
-        const uint32_t *colf = A.lmf + A.lmoff[j];
-        /* (32-bit byte offsets from a wave-uniform base: global_load with an SGPR base instead of a
-         * 64-bit address computed per lane; the tables stay below 4 GB, ensure_lmers checks) */
-        auto col_lmer = [&](int strand, int q) {
-            return *(const uint32_t *)((const char *)colf + (((uint32_t)q + (strand ? A.lm_stride : 0u)) << 2));
-        };
+        for (int x = lane; x < 2 * pkw; x += 64) s_dyn[x] = A.colpk[(size_t)j * 2 * pkw + x];
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
         int s_n = 0, s_hd = 0; /* records in the hit ring and its head (wave-uniform) */
 
         /* one hit record -> accl[m][row slot] += wa * wb.  The lane and bit row of the hit name the
-         * piece (gkm_pack.h), the piece names the row slot and where its l-mers sit in the table */
+         * piece (gkm_pack.h), the piece names the row slot and the row l-mer's distance to its centre */
         auto resolve = [&](uint32_t rec) {
             if (VARIANT & 16) { atomicAdd(&accl[rec_lane(rec)], rec); return; } /* timing: no table reads */
             const int r = rec_lane(rec);
             const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], rec_bit(rec)) : 0;
             const uint32_t slot = lpiece[(r * NP + k) * 2];
-            const uint32_t base = lpiece[(r * NP + k) * 2 + 1]; /* lmoff[row] + p0 - b0*W (mod 2^32) */
-            auto row_lmer = [&](int i0) { return *(const uint32_t *)((const char *)A.lmf + ((base + (uint32_t)i0) << 2)); };
-            const HitValue hv = resolve_hit<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
-                                               rcpT, nB, row_lmer, col_lmer);
-            if (hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
+            const int c0 = (int)lpiece[(r * NP + k) * 2 + 1]; /* (l-mers of the row) / 2 - p0 + b0*W */
+            auto row_win = [&](int i0) {
+                const uint32_t *p = (const uint32_t *)(rowpk_tile + ((uint32_t)r * rpw4 + (((uint32_t)i0 >> 4) << 2)));
+                return pk_window(p[0], p[1], i0);
+            };
+            auto col_win = [&](int strand, int q) {
+                const uint32_t *p = s_dyn + (strand ? pkw : 0) + (q >> 4);
+                return pk_window(p[0], p[1], q);
+            };
+            auto wdist = [&](int dd) { return (uint32_t)((const uint8_t *)s_wd)[dd]; };
+            const HitValue hv = resolve_hit_packed<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
+                                                      rcpT, nB, L, c0, row_win, col_win, wdist);
+            if (VARIANT & 128) { asm volatile("" ::"v"(hv.m), "v"(hv.v), "v"(slot)); return; } /* timing: no accumulate */
+            if (hv.v != 0u && hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
         };
 
-        /* Resolve the hit list in FULL trips of 2 x 64 records with every lane busy: each record gives
-         * up the lowest hit bit of its first non-empty word, what is left of a multi-hit record is
-         * appended again.  Fewer than one trip's worth of records waits in the ring; the last call of
-         * a column (final) empties it. */
+        /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
+         * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
+         * again.  Fewer than one trip's worth of records waits in the ring; the last call of a column
+         * (final) empties it.
+         * No select chains: the position of the first hit is min over the words of ffbl(word) | 32 g
+         * (v_ffbl_b32 gives all ones for an empty word, so empty words lose the min), the number of
+         * hits left is a popcount sum, and a record that goes back to the ring is copied unchanged and
+         * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
         auto trips = [&](bool final) {
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
             while (s_n >= BS_TRIP || (final && s_n > 0)) {
                 const int c = min(s_n, BS_TRIP);
-                uint32_t h[BS_TK][BS_GRP], meta[BS_TK], left[BS_TK];
+                const uint32_t at = ring((uint32_t)(s_hd + lane));
+                uint32_t h[BS_GRP];
+                /* (every ring slot is readable: the lanes past the end of a short, final trip are
+                 * cleared afterwards instead of being masked out of the loads) */
 #pragma unroll
-                for (int k = 0; k < BS_TK; k++) {
-                    const int i = k * 64 + lane;
-                    const uint32_t at = ring((uint32_t)(s_hd + i));
-                    /* (every ring slot is readable: the lanes past the end of a short, final trip
-                     * are cleared afterwards instead of being masked out of the loads) */
+                for (int g = 0; g < BS_GRP; g++) h[g] = s_list[g * BS_CAP + at];
+                const uint32_t meta = s_meta[at];
+                if (c < BS_TRIP) { /* wave-uniform */
 #pragma unroll
-                    for (int g = 0; g < BS_GRP; g++) h[k][g] = s_list[g * BS_CAP + at];
-                    meta[k] = s_meta[at];
-                    if (c < BS_TRIP) { /* wave-uniform */
-#pragma unroll
-                        for (int g = 0; g < BS_GRP; g++) h[k][g] = (i < c) ? h[k][g] : 0u;
-                    }
-                    /* first non-empty word of the record (scanned from the last word down) */
-                    uint32_t hw = h[k][BS_GRP - 1], sel = BS_GRP - 1;
-#pragma unroll
-                    for (int g = BS_GRP - 2; g >= 0; g--) {
-                        const bool take = h[k][g] != 0u;
-                        hw = take ? h[k][g] : hw;
-                        sel = take ? (uint32_t)g : sel;
-                    }
-                    if (hw) resolve((meta[k] + sel) | ((uint32_t)__builtin_ctz(hw) << 24));
-                    const uint32_t cleared = hw & (hw - 1u);
-#pragma unroll
-                    for (int g = 0; g < BS_GRP; g++) h[k][g] = sel == (uint32_t)g ? cleared : h[k][g];
-                    left[k] = h[k][0];
-#pragma unroll
-                    for (int g = 1; g + 1 < BS_GRP; g += 2) left[k] = lop3<TT_OR3>(left[k], h[k][g], h[k][g + 1]);
-                    if (BS_GRP % 2 == 0) left[k] |= h[k][BS_GRP - 1];
+                    for (int g = 0; g < BS_GRP; g++) h[g] = (lane < c) ? h[g] : 0u;
                 }
+                uint32_t first = ffbl_or_ones(h[0]), total = 0u;
+#pragma unroll
+                for (int g = 1; g < BS_GRP; g++) first = min(first, ffbl_or_ones(h[g]) | (uint32_t)(g << 5));
+#pragma unroll
+                for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
+                const uint32_t sel = first >> 5, bit = first & 31u;
+                if (total) resolve((meta + sel) | (bit << 24));
                 s_hd = (int)ring((uint32_t)(s_hd + c));
                 s_n -= c;
+                const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
+                                                               : __ballot(total > 1u);
+                if (more) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                    if (total > 1u) {
+                        const uint32_t to = ring(ring((uint32_t)(s_hd + s_n)) + rank);
 #pragma unroll
-                for (int k = 0; k < BS_TK; k++) {
-                    const unsigned long long more = __ballot(left[k] != 0u);
-                    if (more) {
-                        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                        if (left[k] != 0u) {
-                            const uint32_t at = ring(ring((uint32_t)(s_hd + s_n)) + rank);
-#pragma unroll
-                            for (int g = 0; g < BS_GRP; g++) s_list[g * BS_CAP + at] = h[k][g];
-                            s_meta[at] = meta[k];
-                        }
-                        s_n += (int)__popcll(more);
+                        for (int g = 0; g < BS_GRP; g++) s_list[g * BS_CAP + to] = h[g];
+                        s_meta[to] = meta;
+                        atomicXor(&s_list[sel * BS_CAP + to], 1u << bit); /* ds_xor_b32: that hit is done */
                     }
+                    s_n += (int)__popcll(more);
                 }
             }
         };
@@ -587,21 +655,53 @@ __global__ __launch_bounds__(64, PACKED ? 1 : GKM_BS_WAVES) void k_gram_bitslice
         /* epilogue: one lane per row slot of the tile */
 #pragma unroll
         for (int k = 0; k < NE; k++) {
-            const int rs = k * 64 + lane, row = my_row[k];
+            /* (row and output row of the slot are read here, not kept in registers through the sweep) */
+            const int rs = k * 64 + lane;
+            const int row = rs < nrows ? A.tile_row[tile * gkmpack::MAX_ROWS + rs] : -1;
             if (row < 0 || (j > row && !A.out.write_all)) continue;
             /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
             double g = 0.0;
 #pragma unroll
             for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)accl[m * NSLOT + rs];
-            const int64_t r = A.out.local_rows ? my_out[k] : row;
+            const int64_t r = A.out.local_rows ? A.tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
             if (A.out.diag && j == row) A.out.diag[row] = g;
-            if (A.out.G) A.out.G[r * A.out.ld + j] = g;
+            if (A.S) A.S[(A.tile_soff[tile] + (j - A.tile_cbeg[tile])) * NSLOT + rs] = g;
             if (A.out.P) {
 #pragma unroll
                 for (int m = 0; m <= D; m++)
                     A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)accl[m * NSLOT + rs];
             }
         }
+    }
+}
+
+/* S (tile-transposed, see BsArgs) -> rows of G.  Block = 64 columns x 64 row slots of one tile, moved
+ * through LDS so that both the reads (64 slots of one column) and the writes (64 columns of one row)
+ * are 512-byte runs.  grid (column blocks, tiles * NSLOT / 64). */
+template <int NSLOT>
+__global__ __launch_bounds__(256) void k_untile(const double *__restrict__ S, const int64_t *__restrict__ tile_soff,
+                                                const int *__restrict__ tile_cbeg, const int *__restrict__ tile_cend,
+                                                const int *__restrict__ tile_nrows, const int *__restrict__ tile_row,
+                                                const int *__restrict__ tile_out, GramOut out)
+{
+    __shared__ double buf[64][65];
+    const int tile = blockIdx.y / (NSLOT / 64), half = blockIdx.y % (NSLOT / 64);
+    const int cbeg = tile_cbeg[tile], cend = tile_cend[tile], nrows = tile_nrows[tile];
+    const int jb = cbeg + (int)blockIdx.x * 64;
+    if (jb >= cend || half * 64 >= nrows) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const double *src = S + (tile_soff[tile] + (jb - cbeg)) * NSLOT + half * 64;
+    for (int c = ty; c < 64; c += 4)
+        if (jb + c < cend && half * 64 + tx < nrows) buf[c][tx] = src[(int64_t)c * NSLOT + tx];
+    __syncthreads();
+    for (int rl = ty; rl < 64; rl += 4) {
+        const int rs = half * 64 + rl;
+        if (rs >= nrows) break;
+        const int row = tile_row[tile * gkmpack::MAX_ROWS + rs];
+        const int j = jb + tx;
+        if (j >= cend || (j > row && !out.write_all)) continue;
+        const int64_t r = out.local_rows ? tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
+        out.G[r * out.ld + j] = buf[tx][rl];
     }
 }
 
@@ -739,11 +839,14 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipMemcpyAsync(ctx->lmoff.p, ctx->h_lmoff.data(), ((size_t)n + 1) * sizeof(int64_t),
                           hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(ctx->len.p, ctx->h_len.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetAsync(ctx->wd.p, 0, WD_LDS, stream));
+    /* unweighted kernel types: every positional weight is 1 (libgkm.c:926-932) -- a table of ones keeps the
+     * hit path free of a weighted / unweighted branch */
+    HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
     if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
-    ctx->wd_len = weighted ? wdist_len : 0;
+    ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
     ctx->have_lmers = false;
     ctx->have_sb = false;
+    ctx->have_colpk = false;
     return 0;
 }
 
@@ -760,6 +863,20 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
                        ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
     HIPCHK(hipGetLastError());
     ctx->have_lmers = true;
+    return 0;
+}
+
+static int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->have_colpk) return 0;
+    /* one word more than the bases need: the hit path reads words q/16 and q/16 + 1 */
+    const int pkw = (ctx->maxlen + 15) / 16 + 1;
+    if (ctx->colpk.ensure((size_t)ctx->n * 2 * (size_t)pkw)) return 4;
+    hipLaunchKernelGGL(k_pack_strands, dim3((unsigned)ctx->n * 2), dim3(64), 0, stream, ctx->codes.p, ctx->off.p, pkw,
+                       ctx->colpk.p);
+    HIPCHK(hipGetLastError());
+    ctx->pkw = pkw;
+    ctx->have_colpk = true;
     return 0;
 }
 
@@ -797,6 +914,8 @@ static bs_kernel_t pick_bitslice(int L, int d)
         if (vi == 2) return k_gram_bitslice<W, 11, 3, PACKED, 2>;
         if (vi == 16) return k_gram_bitslice<W, 11, 3, PACKED, 16>;
         if (vi == 32) return k_gram_bitslice<W, 11, 3, PACKED, 32>;
+        if (vi == 64) return k_gram_bitslice<W, 11, 3, PACKED, 64>;
+        if (vi == 128) return k_gram_bitslice<W, 11, 3, PACKED, 128>;
     }
 #endif
     /* every (L, d) the parameter check admits (3 <= L <= 12, d <= min(4, L - 1)), plus (12, 6) for the
@@ -848,7 +967,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
         const int NP = packed ? gkmpack::MAX_PIECES : 1;
         bs_kernel_t bs = packed ? bs10 : pick_bitslice<10, false>(L, d);
-        if (ensure_sb(ctx, W, stream) || ensure_lmers(ctx, stream)) return 4;
+        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
         std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)NP * 2, 0u);
@@ -859,57 +978,85 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
             lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
             lane_piece[((size_t)pc.lane * NP + k) * 2] = (uint32_t)pc.slot;
+            /* the row l-mer at lane position i0 is |c0 - i0| l-mers away from its sequence's centre l-mer */
             lane_piece[((size_t)pc.lane * NP + k) * 2 + 1] =
-                (uint32_t)(ctx->h_lmoff[(size_t)pc.row] + pc.p0 - (int64_t)pc.b0 * W);
+                (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W);
         }
-        if (ctx->scratch[ctx->sel].piece_desc.ensure(desc.size()) || ctx->scratch[ctx->sel].lane_mask.ensure(nl) || ctx->scratch[ctx->sel].lane_piece.ensure(lane_piece.size()) ||
-            ctx->scratch[ctx->sel].tile_row.ensure(pk.tile_row.size()) || ctx->scratch[ctx->sel].tile_out.ensure(pk.tile_out.size()) ||
-            ctx->scratch[ctx->sel].tile_nrows.ensure((size_t)ntiles) || ctx->scratch[ctx->sel].tile_cbeg.ensure((size_t)ntiles) || ctx->scratch[ctx->sel].tile_cend.ensure((size_t)ntiles) ||
-            ctx->scratch[ctx->sel].rowplanes.ensure(nl * 3 * W))
-            return 4;
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].piece_desc.p, desc.data(), desc.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].lane_mask.p, lane_mask.data(), nl * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].lane_piece.p, lane_piece.data(), lane_piece.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_row.p, pk.tile_row.data(), pk.tile_row.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_out.p, pk.tile_out.data(), pk.tile_out.size() * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_nrows.p, pk.tile_nrows.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
+        /* columns [cbeg, cend) per tile */
         std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
-        int span = 0;
+        std::vector<int64_t> soff((size_t)ntiles + 1, 0);
         for (int t = 0; t < ntiles; t++) {
             int amin = n;
             for (int rs = 0; rs < pk.tile_nrows[(size_t)t]; rs++) amin = std::min(amin, pk.tile_row[(size_t)t * gkmpack::MAX_ROWS + rs]);
             cbeg[(size_t)t] = mode == COLS_DIAGONAL ? amin : 0;
             cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
-            span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
+            soff[(size_t)t + 1] = soff[(size_t)t] + (cend[(size_t)t] - cbeg[(size_t)t]);
         }
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_cbeg.p, cbeg.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].tile_cend.p, cend.data(), (size_t)ntiles * sizeof(int), hipMemcpyHostToDevice, stream));
-        /* the host vectors above are pageable: the copies have completed on return */
-        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 3), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, ctx->scratch[ctx->sel].piece_desc.p, W, ctx->scratch[ctx->sel].rowplanes.p);
+        if (soff[(size_t)ntiles] <= 0 || soff[(size_t)ntiles] > 0x7fffffffLL) return set_err_msg("gram: bad work item count", 2);
+
+        /* every per-launch table goes to the device in ONE copy (the boundary call issues 13 launches) */
+        std::vector<char> blob;
+        auto put = [&](const void *src, size_t bytes) {
+            const size_t at = (blob.size() + 255) & ~(size_t)255;
+            blob.resize(at + bytes);
+            memcpy(blob.data() + at, src, bytes);
+            return at;
+        };
+        const size_t o_desc = put(desc.data(), desc.size() * sizeof(int));
+        const size_t o_mask = put(lane_mask.data(), nl * sizeof(uint32_t));
+        const size_t o_piece = put(lane_piece.data(), lane_piece.size() * sizeof(uint32_t));
+        const size_t o_trow = put(pk.tile_row.data(), pk.tile_row.size() * sizeof(int));
+        const size_t o_tout = put(pk.tile_out.data(), pk.tile_out.size() * sizeof(int));
+        const size_t o_tn = put(pk.tile_nrows.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_cbeg = put(cbeg.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
+        const int NS = packed ? gkmpack::MAX_ROWS : 64;
+        auto &scr = ctx->scratch[ctx->sel];
+        const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
+        if (scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) || scr.rowpk.ensure(nl * (size_t)rpw) ||
+            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
+            return 4;
+        HIPCHK(hipMemcpyAsync(scr.tables.p, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
+        /* (pageable source: the copy has been staged by the time the call returns) */
+        char *tb = scr.tables.p;
+        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
+                           ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
         HIPCHK(hipGetLastError());
 
         BsArgs A;
-        A.rowplanes = ctx->scratch[ctx->sel].rowplanes.p; A.lane_mask = ctx->scratch[ctx->sel].lane_mask.p; A.lane_piece = ctx->scratch[ctx->sel].lane_piece.p;
-        A.tile_row = ctx->scratch[ctx->sel].tile_row.p; A.tile_out = ctx->scratch[ctx->sel].tile_out.p; A.tile_nrows = ctx->scratch[ctx->sel].tile_nrows.p;
-        A.tile_cbeg = ctx->scratch[ctx->sel].tile_cbeg.p; A.tile_cend = ctx->scratch[ctx->sel].tile_cend.p;
-        A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride; A.lm_stride = ctx->lm_stride; A.lmoff = ctx->lmoff.p;
+        A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
+        A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
+        A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
+        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd32 = (const uint32_t *)ctx->wd.p;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
-        /* one column sequence per work item: a wave of the full-size problem lives ~0.6 ms (2.3 ms with four
-         * columns), which is what the drain at the end of every launch costs -- nothing for one big launch
-         * (config 2: 84.3 vs 85.4 ms) but ~1 ms per launch for the boundary's 13 row blocks (106 -> 96 ms per
-         * call) and for the chunks of the multi-GPU path */
-        A.cj = 1;
-        const char *e = getenv("GKM_CJ");
-        if (e && atoi(e) > 0) A.cj = atoi(e);
-        const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
+        A.ntiles = ntiles;
+        const size_t dyn_lds = (size_t)(2 * A.pkw + A.wd_words) * sizeof(uint32_t);
+        A.S = out.G ? scr.S.p : nullptr;
+        A.tile_soff = (const int64_t *)(tb + o_soff);
+        /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
+         * the drain at the end of every launch costs -- nothing for one big launch, but the boundary call
+         * issues 13 launches and the multi-GPU path one per chunk. */
         HIPCHK(hipEventRecord(ctx->ev0, stream));
-        hipLaunchKernelGGL(bs, dim3(nchunks, (unsigned)ntiles), dim3(64), 0, stream, A);
+        hipLaunchKernelGGL(bs, dim3((unsigned)soff[(size_t)ntiles]), dim3(64), dyn_lds, stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, stream));
+        if (out.G) {
+            int span = 0;
+            for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
+            const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / 64)));
+            if (packed)
+                hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
+                                   A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, out);
+            else
+                hipLaunchKernelGGL(k_untile<64>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
+                                   A.tile_nrows, A.tile_row, A.tile_out, out);
+            HIPCHK(hipGetLastError());
+        }
         ctx->last_kernel = packed ? "k_gram_bitslice<packed>" : "k_gram_bitslice";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;

@@ -35,8 +35,12 @@ from . import device
 _KMAT = None  # shared with forked CV workers, like the reference's module global
 
 
-def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False):
-    """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity]."""
+def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1):
+    """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity].
+
+    gpus > 1 (or a list of device ordinals): the matrix is computed on that many GPUs of the node by
+    this one process (row-block sharding + RCCL all-gather behind the C ABI, include/gkm_hip.h
+    gkmhip_gram_allgather) and the copy on device `gpus[0]` is returned -- bit-identical to gpus=1."""
     kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, nproc, verbosity = args_gkm
     if backend == "boundary":
         seqs, n_pos, _, _ = device.read_problem(pos_fa, neg_fa)
@@ -58,9 +62,14 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False):
     if n_pos == 0 or n_pos == len(seqs):
         logging.error("error on kernel construction")
         sys.exit()
-    res = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=gpu)
-    K = res["K"]                               # lower triangle + unit diagonal, zeros above
-    K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97
+    devices = list(gpus) if isinstance(gpus, (list, tuple)) else list(range(gpu, gpu + int(gpus)))
+    if len(devices) > 1:
+        res = device.gram_matrix_multi(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), devices=devices)
+        K = res["K"][0]
+        del res
+    else:
+        K = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=devices[0])["K"]
+    K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97 (lower triangle + unit diagonal, zeros above)
     if resident:
         return K, n_pos, len(seqs) - n_pos
     return K.cpu().numpy(), n_pos, len(seqs) - n_pos
@@ -123,7 +132,8 @@ def init(pos_fa, neg_fa, args):
     args_gkm = [args.kernel_type, args.full_word_length, args.non_gap_length, args.max_num_gaps, args.init_decay,
                 args.half_life_decay, args.rbf_gamma, pos_fa, neg_fa, args.n_processes, args.verbosity]
     logging.info("%s: building up kernel matrix", pos_fa)
-    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm, resident=getattr(args, "svm_solver", "gpu") == "gpu")
+    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm, resident=getattr(args, "svm_solver", "gpu") == "gpu",
+                                              gpus=getattr(args, "gpus", 1))
     args_svm = [args.regularization, args.precision, args.shrinking, args.cache_size, args.ncv, args.repeats,
                 args.fast_estimation, args.random_seeds, args.n_processes]
     logging.info("%s: svm training", pos_fa)
@@ -227,6 +237,8 @@ def build_parser():
     v.add_argument("-r", "--repeats", type=int, default=1, help="repeats of CV training (default: 1)")
     v.add_argument("--svm-solver", choices=("gpu", "sklearn"), default="gpu",
                    help="gpu: all folds on the GPU-resident matrix (default); sklearn: the reference's solver")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="GPUs of this node that share the kernel matrix (row blocks + RCCL all-gather; default: 1)")
     v.add_argument("-f", "--fast-estimation", type=int, default=0, help="not supported (dead code in the reference)")
     return parser
 

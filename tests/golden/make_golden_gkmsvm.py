@@ -45,6 +45,37 @@ def make_inputs():
     return pf, nf
 
 
+def c4_fixture(ref):
+    """BASELINE configs[3] stand-in at its real size: ONE `gkmqc.py evaluate` subset (5 000 peak-like
+    positives + 5 000 matched nulls x 600 bp, wgkm L=10 k=6 d=3, 5-fold CV; reference
+    bin/gkmqc.py:150-154,181-185,213-215) through the reference's OWN module: kernel matrix by the
+    compiled reference, cross-validation by its scikit-learn harness."""
+    import time
+    from gkmqc_amd import synth
+    tmp = os.path.join(ROOT, "gpurun_out", "golden_tmp")
+    os.makedirs(tmp, exist_ok=True)
+    pf, nf = os.path.join(tmp, "c4_p.fa"), os.path.join(tmp, "c4_n.fa")
+    synth.write_peak_problem(pf, nf, 5000, 5000, 600)
+    threads = int(os.environ.get("GKM_GOLDEN_THREADS", "6"))
+    t0 = time.time()
+    kmat, n_pos, n_neg = ref.computeGkmKernel([4, 10, 6, 3, 50, 50, 1.0, pf, nf, threads, 0])
+    t1 = time.time()
+    svm = [1.0, 0.001, 0, 512, 5, 1, 0, 1, 5]
+    auc, std = ref.crossValidate(list(svm), kmat, n_pos, n_neg)
+    t2 = time.time()
+    rng = np.random.default_rng(5)
+    ii, jj = rng.integers(0, kmat.shape[0], 300), rng.integers(0, kmat.shape[0], 300)
+    out = {"c4_peaks": {
+        "args_gkm": [4, 10, 6, 3, 50, 50, 1.0, "<synth.write_peak_problem 5000+5000 x 600>", "", threads, 0],
+        "args_svm": svm, "n_pos": int(n_pos), "n_neg": int(n_neg), "auc_mean": float(auc), "auc_std": float(std),
+        "kmat_sha256": hashlib.sha256(np.ascontiguousarray(kmat).tobytes()).hexdigest(),
+        "kmat_min": float(kmat.min()), "kmat_sum": float(kmat.sum()),
+        "sample_i": ii.tolist(), "sample_j": jj.tolist(), "sample_v": [float(kmat[a, b]) for a, b in zip(ii, jj)],
+        "ref_kernel_wall_s": t1 - t0, "ref_cv_wall_s": t2 - t1, "ref_threads": threads}}
+    json.dump(out, open(os.path.join(HERE, "gkmsvm_expected_c4.json"), "w"), indent=1)
+    print("c4_peaks", n_pos, n_neg, auc, std, "kernel %.0f s, cv %.0f s" % (t1 - t0, t2 - t1))
+
+
 def main():
     assert O.have_ref(), "run `make -C oracle ref` first"
     if os.path.isdir(TREE):
@@ -56,6 +87,8 @@ def main():
     sys.path.insert(0, os.path.join(TREE, "scripts"))
     import gkmsvm as ref  # the reference's module
 
+    if "--c4" in sys.argv:
+        return c4_fixture(ref)
     pf, nf = make_inputs()
     out = {}
     for name, gkm, svm in (

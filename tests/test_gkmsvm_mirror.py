@@ -86,3 +86,32 @@ def test_init_many_overlaps_and_matches_init(built, tmp_path):
     assert got == want
     assert abs(got[0][0] - case["auc_mean"]) < 1e-12
     assert open(str(tmp_path / "seq") + ".gkmqc.eval.out").read() == open(str(tmp_path / "ovl") + ".gkmqc.eval.out").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("gpus", [1, [0, 0]])
+def test_config4_stand_in_at_full_size(built, tmp_path, gpus):
+    """BASELINE configs[3] at its real size: ONE `gkmqc.py evaluate` subset (5 000 peak-like positives +
+    5 000 matched nulls x 600 bp, wgkm L=10 k=6 d=3, 5-fold CV; reference bin/gkmqc.py:150-154,181-185,
+    213-215).  Expected numbers come from the reference's OWN module on the same files
+    (tests/golden/make_golden_gkmsvm.py --c4: compiled reference for the matrix, its scikit-learn harness
+    for the AUC): the symmetrised matrix must be bit-identical, the AUC equal.  gpus=[0, 0]: the same
+    through the one-process multi-GPU entry (two contexts on the box's one GPU)."""
+    import hashlib
+    import torch
+    from gkmqc_amd import gkmsvm, synth
+    case = json.load(open(os.path.join(helpers.GOLDEN, "gkmsvm_expected_c4.json")))["c4_peaks"]
+    pf, nf = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+    synth.write_peak_problem(pf, nf, 5000, 5000, 600)
+    a = list(case["args_gkm"])
+    a[7], a[8] = pf, nf
+    K, n_pos, n_neg = gkmsvm.computeGkmKernel(a, resident=True, gpus=gpus)
+    assert (n_pos, n_neg) == (case["n_pos"], case["n_neg"])
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), K, n_pos, n_neg)      # every fold on the GPU
+    assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
+    kmat = K.cpu().numpy()
+    del K
+    torch.cuda.empty_cache()
+    assert helpers.max_rel_err(kmat[case["sample_i"], case["sample_j"]], np.array(case["sample_v"])) < 1e-12
+    assert hashlib.sha256(np.ascontiguousarray(kmat).tobytes()).hexdigest() == case["kmat_sha256"], \
+        "matrix differs from the reference's in the last bits"

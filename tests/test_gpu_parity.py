@@ -157,7 +157,10 @@ def test_boundary_end_to_end(dev):
 
 FULL_CONFIGS = {"c2": (5000, 5000, 300, None, 4, 11, 7, 3),       # BASELINE.json configs[1] (the headline)
                 "c3": (10000, 10000, 300, None, 4, 11, 7, 3),     # configs[2]
-                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4)}  # configs[4]
+                "c5": (5000, 5000, None, (150, 600), 4, 12, 8, 4),  # configs[4]
+                # configs[3] stand-in: one `gkmqc.py evaluate` subset on peak-like sequences (reference
+                # bin/gkmqc.py:150-154,181-185; generator gkmqc_amd.synth.make_peak_sequences)
+                "c4": (5000, 5000, 600, None, 4, 10, 6, 3)}
 
 
 @pytest.mark.parametrize("name", sorted(FULL_CONFIGS))
@@ -170,7 +173,12 @@ def test_full_size_against_reference_digest(dev, name):
         pytest.skip("digest fixture missing")
     z = np.load(path)
     npos, nneg, ln, lr, t, L, k, d = FULL_CONFIGS[name]
-    seqs = helpers.synth_codes(npos, nneg, ln or 300, lr)
+    if name == "c4":
+        from gkmqc_amd import synth
+        seqs = [dev.encode(x) for x in synth.make_peak_sequences(11, npos, ln, True) +
+                synth.make_peak_sequences(12, nneg, ln, False)]
+    else:
+        seqs = helpers.synth_codes(npos, nneg, ln or 300, lr)
     res = dev.gram_matrix(seqs, t, L, k, d)
     K = res["K"].cpu().numpy()
     del res["K"]

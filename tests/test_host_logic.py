@@ -147,3 +147,14 @@ def test_product_does_not_reference_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "gkm_oracle" not in txt and "from oracle" not in txt \
                     and "import oracle" not in txt and "_ref/" not in txt, os.path.join(dirpath, f)
+
+
+def test_no_timing_variants_in_the_product(built):
+    """The ablation kernels (template parameter VARIANT != 0: parts of the work skipped, WRONG results) and
+    the GKM_VARIANT switch that selects them exist only in -DGKM_TIMING_VARIANTS builds under
+    build_variants/ (tools/variants.sh); the drop-in library must hold VARIANT = 0 instantiations only."""
+    import re
+    blob = open(os.path.join(ROOT, "gkmqc_amd", "bin", "gkmkern_pylib.so"), "rb").read()
+    names = set(re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELb[01]ELi(\d+)EEv6BsArgs", blob))
+    assert names == {b"0"}, names
+    assert b"GKM_VARIANT" not in blob
