@@ -214,7 +214,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
 {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
+    /* (hipFree waits for the work that may still use the buffers; no separate device-wide wait) */
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release();
     ctx->scratch[0].release(); ctx->scratch[1].release(); ctx->sq.release();

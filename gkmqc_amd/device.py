@@ -352,14 +352,38 @@ def cross_kernel(seqs, rows, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devi
         ctx.close()
 
 
+_CTX_CACHE = {}
+
+
+def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0):
+    """One long-lived GramContext per (device, parameters).  Destroying a context frees device memory,
+    which waits for EVERYTHING on the device (hipFree): a caller that evaluates subset after subset
+    with the cross-validation of the previous one still running on another stream (gkmsvm.init_many)
+    keeps its context instead, re-uploads the next subset's sequences into the same buffers and so
+    never blocks on the other stream."""
+    key = (device, kernel_type, L, k, d, int(M), float(H), float(gamma))
+    ctx = _CTX_CACHE.get(key)
+    if ctx is None or not ctx.handle:
+        ctx = _CTX_CACHE[key] = GramContext(kernel_type, L, k, d, M, H, gamma, device)
+    return ctx
+
+
+def release_cached_contexts():
+    for ctx in _CTX_CACHE.values():
+        ctx.close()
+    _CTX_CACHE.clear()
+
+
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,
-                kernel=KERNEL_AUTO, symmetric=False):
+                kernel=KERNEL_AUTO, symmetric=False, keep_context=False):
     """Whole Gram matrix of `seqs` on one GPU (device memory through torch).
 
     Returns dict(K=torch fp64 [n,n] (lower triangle + unit diagonal; upper too if symmetric),
-    P=int32 [n,n,d+1] or None, sqnorm=[n], kernel=name, ms=device ms of the gram kernel)."""
+    P=int32 [n,n,d+1] or None, sqnorm=[n], kernel=name, ms=device ms of the gram kernel).
+    keep_context: use (and keep) the cached context of these parameters, see cached_context()."""
     import torch
-    ctx = GramContext(kernel_type, L, k, d, M, H, gamma, device)
+    ctx = (cached_context(kernel_type, L, k, d, M, H, gamma, device) if keep_context
+           else GramContext(kernel_type, L, k, d, M, H, gamma, device))
     try:
         ctx.set_kernel(kernel)
         dev = torch.device("cuda", device)
@@ -376,7 +400,8 @@ def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, w
             return dict(K=G, P=P, sqnorm=sq, kernel=ctx.last_kernel_name(), ms=ctx.last_kernel_ms(),
                         comparisons=ctx.last_comparisons())
     finally:
-        ctx.close()
+        if not keep_context:
+            ctx.close()
 
 
 def gram_matrix_multi(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devices=(0,), symmetric=False, chunks=0,

@@ -35,7 +35,7 @@ from . import device
 _KMAT = None  # shared with forked CV workers, like the reference's module global
 
 
-def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1):
+def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, keep_context=False):
     """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity].
 
     gpus > 1 (or a list of device ordinals): the matrix is computed on that many GPUs of the node by
@@ -68,7 +68,8 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1):
         K = res["K"][0]
         del res
     else:
-        K = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=devices[0])["K"]
+        K = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=devices[0],
+                               keep_context=keep_context)["K"]
     K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97 (lower triangle + unit diagonal, zeros above)
     if resident:
         return K, n_pos, len(seqs) - n_pos
@@ -194,7 +195,8 @@ def init_many(pairs, args, gpu=0):
                         args.init_decay, args.half_life_decay, args.rbf_gamma, pos_fa, neg_fa, args.n_processes,
                         args.verbosity]
             with torch.cuda.stream(gram_stream):
-                K, n_pos, n_neg = computeGkmKernel(args_gkm, gpu=gpu, resident=True)
+                # (one context for all subsets: closing one would wait for the other stream's solver, hipFree)
+                K, n_pos, n_neg = computeGkmKernel(args_gkm, gpu=gpu, resident=True, keep_context=True)
                 gram_stream.synchronize()
             handoff.put((s, K, n_pos, n_neg))
             del K
