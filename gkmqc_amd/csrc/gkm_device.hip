@@ -450,14 +450,14 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
      * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
      * of the row lane's packed positions from global memory (5.4 KB per tile, L1 resident: the waves of a CU
      * work on the same tile). */
-    extern __shared__ uint32_t s_dyn[]; /* [2 * pkw] column strands (forward, reverse complement), then wd_words */
+    extern __shared__ uint32_t s_dyn[]; /* [wd_words] weight bytes, then [2 * pkw] column strands (forward, reverse complement) */
     /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
      * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
      * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
      * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
      * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
     __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
-    uint32_t *const s_meta = s_list + BS_GRP * BS_CAP; /* first word of the group, delta, strand, row lane */
+    /* (array BS_GRP of s_list: first word of the group, delta, strand, row lane) */
     /* PACKED: lanes may hold several pieces (gkm_pack.h) and a tile up to MAX_ROWS rows.  When no
      * lane of the call holds more than one piece (e.g. every fixed-length data set) the leaner
      * variant runs: one (slot, base) pair per lane, at most 64 rows per tile, 3 KB less LDS
@@ -503,8 +503,11 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
     for (int k = 0; k < NP * 2; k++) lpiece[lane * NP * 2 + k] = A.lane_piece[(size_t)(tile * 64 + lane) * NP * 2 + k];
     const uint32_t lane_tag = (uint32_t)lane << 18;
     const int pkw = A.pkw;
-    uint32_t *const s_wd = s_dyn + 2 * pkw;
-    for (int x = lane; x < A.wd_words; x += 64) s_wd[x] = A.wd32[x];
+    /* the weight table sits at the start of the dynamic LDS: its address is a constant of the kernel and
+     * folds into the offset field of the byte reads */
+    uint32_t *const s_col = s_dyn + A.wd_words;
+    for (int x = lane; x < A.wd_words; x += 64) s_dyn[x] = A.wd32[x];
+    const uint32_t lane4 = (uint32_t)lane << 2, pkw4 = (uint32_t)pkw * 4u;
     /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
      * base instead of a 64-bit address computed per lane) */
     const char *const rowpk_tile = (const char *)(A.rowpk + (size_t)tile * 64 * A.rpw);
@@ -514,33 +517,51 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
         const int T = A.len[j];
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
-        for (int x = lane; x < 2 * pkw; x += 64) s_dyn[x] = A.colpk[(size_t)j * 2 * pkw + x];
+        for (int x = lane; x < 2 * pkw; x += 64) s_col[x] = A.colpk[(size_t)j * 2 * pkw + x];
+        /* weight of a column l-mer q: forward strand wd[|nB/2 - q|]; reverse strand wt_rc[q] = wt[nB-1-q]
+         * (libgkm.c:924) = wd[|nB/2 - (nB-1-q)|] = wd[|q - (nB/2 - [nB even])|] */
+        const uint32_t ccen = (uint32_t)(nB / 2), ceven = (nB & 1) ? 0u : 1u;
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
         int s_n = 0, s_hd = 0; /* records in the hit ring and its head (wave-uniform) */
 
-        /* one hit record -> accl[m][row slot] += wa * wb.  The lane and bit row of the hit name the
-         * piece (gkm_pack.h), the piece names the row slot and the row l-mer's distance to its centre */
-        auto resolve = [&](uint32_t rec) {
-            if (VARIANT & 16) { atomicAdd(&accl[rec_lane(rec)], rec); return; } /* timing: no table reads */
-            const int r = rec_lane(rec);
-            const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], rec_bit(rec)) : 0;
-            const uint32_t slot = lpiece[(r * NP + k) * 2];
-            const int c0 = (int)lpiece[(r * NP + k) * 2 + 1]; /* (l-mers of the row) / 2 - p0 + b0*W */
-            auto row_win = [&](int i0) {
-                const uint32_t *p = (const uint32_t *)(rowpk_tile + ((uint32_t)r * rpw4 + (((uint32_t)i0 >> 4) << 2)));
-                return pk_window(p[0], p[1], i0);
-            };
-            auto col_win = [&](int strand, int q) {
-                const uint32_t *p = s_dyn + (strand ? pkw : 0) + (q >> 4);
-                return pk_window(p[0], p[1], q);
-            };
-            auto wdist = [&](int dd) { return (uint32_t)((const uint8_t *)s_wd)[dd]; };
-            const HitValue hv = resolve_hit_packed<W>(rec_bit(rec), rec_w(rec), rec_delta(rec), rec_strand(rec), (uint32_t)T,
-                                                      rcpT, nB, L, c0, row_win, col_win, wdist);
-            if (VARIANT & 128) { asm volatile("" ::"v"(hv.m), "v"(hv.v), "v"(slot)); return; } /* timing: no accumulate */
-            if (hv.v != 0u && hv.m <= D) atomicAdd(&accl[hv.m * NSLOT + slot], hv.v); /* LDS atomic: ds_add_u32 */
+        /* One hit -> accl[m][row slot] += wa * wb.  (meta + sel, bit) name the row lane r, the lane position
+         * i0 = bit*W + w of the window, the shift and the strand; lane and bit row name the piece (gkm_pack.h),
+         * the piece names the row slot and c0, which makes |c0 - i0| the row l-mer's distance to its sequence's
+         * centre l-mer (libgkm.c:912-925 depends on nothing else).  Written for the instruction count -- the
+         * kernel is bound by VALU issue, and a trip's ~60 instructions per 64 hits are a sixth of all it
+         * executes: 24-bit multiply-adds, |a - b| + c as one v_sad_u32, funnel shifts that mask their own shift
+         * count, the weight table at a constant LDS offset.  Same arithmetic as resolve_hit_packed
+         * (gkm_bitslice.h), which the CPU tests run against the oracle. */
+        auto resolve = [&](uint32_t meta, uint32_t sel, uint32_t bit) {
+            const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 6 bits */
+            if (VARIANT & 16) { atomicAdd(&accl[rec_lane(ms)], ms | (bit << 24)); return; } /* timing: no table reads */
+            const uint32_t r = (ms >> 18) & 63u;
+            const uint32_t smask = (uint32_t)((int32_t)(ms << 14) >> 31); /* all ones on the reverse strand (v_bfe_i32) */
+            const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], (int)bit) : 0;
+            const uint32_t slot4 = lpiece[(r * NP + k) * 2];    /* row slot * 4 */
+            const uint32_t c0b = lpiece[(r * NP + k) * 2 + 1];  /* (l-mers of the row) / 2 - p0 + b0*W + 2048 */
+            const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 63u);
+            const uint32_t x = i0 + ((ms >> 6) & 2047u);
+            uint32_t q;
+            if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
+            else q = mod_small(x, (uint32_t)T, rcpT);
+            /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
+            if ((int)q < nB) {
+                const uint32_t *rw = (const uint32_t *)(rowpk_tile + (__umul24(r, rpw4) + ((i0 >> 2) & ~3u)));
+                const uint32_t *cw = (const uint32_t *)((const char *)s_col + ((smask & pkw4) + ((q >> 2) & ~3u)));
+                const uint8_t *wdb = (const uint8_t *)s_dyn;
+                const uint32_t wa = wdb[__usad(c0b, i0 + 2048u, 0u)];
+                const uint32_t wb = wdb[__usad(q, ccen - (smask & ceven), 0u)];
+                /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
+                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], i0 << 1);
+                const uint32_t eb = __builtin_amdgcn_alignbit(cw[1], cw[0], q << 1);
+                const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
+                if (VARIANT & 128) { asm volatile("" ::"v"(m), "v"(wa), "v"(wb), "v"(slot4)); return; } /* timing: no accumulate */
+                if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 */
+                    atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+            }
         };
 
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
@@ -555,13 +576,14 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
             while (s_n >= BS_TRIP || (final && s_n > 0)) {
                 const int c = min(s_n, BS_TRIP);
-                const uint32_t at = ring((uint32_t)(s_hd + lane));
+                static_assert(BS_CAP_POW2, "ring offsets wrap with one AND");
+                const char *const at = (const char *)s_list + ((((uint32_t)s_hd << 2) + lane4) & (uint32_t)(BS_CAP * 4 - 1));
                 uint32_t h[BS_GRP];
                 /* (every ring slot is readable: the lanes past the end of a short, final trip are
                  * cleared afterwards instead of being masked out of the loads) */
 #pragma unroll
-                for (int g = 0; g < BS_GRP; g++) h[g] = s_list[g * BS_CAP + at];
-                const uint32_t meta = s_meta[at];
+                for (int g = 0; g < BS_GRP; g++) h[g] = *(const uint32_t *)(at + g * BS_CAP * 4);
+                const uint32_t meta = *(const uint32_t *)(at + BS_GRP * BS_CAP * 4);
                 if (c < BS_TRIP) { /* wave-uniform */
 #pragma unroll
                     for (int g = 0; g < BS_GRP; g++) h[g] = (lane < c) ? h[g] : 0u;
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
 #pragma unroll
                 for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
                 const uint32_t sel = first >> 5, bit = first & 31u;
-                if (total) resolve((meta + sel) | (bit << 24));
+                if (total) resolve(meta, sel, bit);
                 s_hd = (int)ring((uint32_t)(s_hd + c));
                 s_n -= c;
                 const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
@@ -581,11 +603,11 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
                                                                     __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                     if (total > 1u) {
-                        const uint32_t to = ring(ring((uint32_t)(s_hd + s_n)) + rank);
+                        char *const to = (char *)s_list + (((rank << 2) + ((uint32_t)(s_hd + s_n) << 2)) & (uint32_t)(BS_CAP * 4 - 1));
 #pragma unroll
-                        for (int g = 0; g < BS_GRP; g++) s_list[g * BS_CAP + to] = h[g];
-                        s_meta[to] = meta;
-                        atomicXor(&s_list[sel * BS_CAP + to], 1u << bit); /* ds_xor_b32: that hit is done */
+                        for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
+                        *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
+                        atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
                     }
                     s_n += (int)__popcll(more);
                 }
@@ -977,10 +999,11 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             int *dd = &desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
             dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
             lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
-            lane_piece[((size_t)pc.lane * NP + k) * 2] = (uint32_t)pc.slot;
-            /* the row l-mer at lane position i0 is |c0 - i0| l-mers away from its sequence's centre l-mer */
+            lane_piece[((size_t)pc.lane * NP + k) * 2] = (uint32_t)pc.slot * 4u; /* byte offset into accl[m][.] */
+            /* the row l-mer at lane position i0 is |c0 - i0| l-mers away from its sequence's centre l-mer;
+             * c0 > -2048, stored with a bias of 2048 so that the kernel's unsigned |a - b| applies */
             lane_piece[((size_t)pc.lane * NP + k) * 2 + 1] =
-                (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W);
+                (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
         }
         /* columns [cbeg, cend) per tile */
         std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
