@@ -424,7 +424,7 @@ constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
                           config 2 with the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 */
 #endif
 #ifndef GKM_BS_PACKED_WAVES
-#define GKM_BS_PACKED_WAVES 1 /* several-pieces-per-lane kernel: no register cap asked (it takes ~90 VGPRs -> 5 waves) */
+#define GKM_BS_PACKED_WAVES 6 /* several-pieces-per-lane kernels: 75-78 VGPRs */
 #endif
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 
@@ -436,9 +436,12 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
  * control flow besides the push.
  */
-template <int W, int L, int D, bool PACKED, int VARIANT = 0>
-__global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+template <int W, int L, int D, int PK, int VARIANT = 0>
+__global__ __launch_bounds__(64, PK ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
+    /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
+     *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile */
+    constexpr bool PACKED = PK != 0;
     /* VARIANT (timing experiments only, -DGKM_TIMING_VARIANTS builds, selected by GKM_VARIANT; results are
      * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
@@ -458,14 +461,19 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
      * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
     __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
     /* (array BS_GRP of s_list: first word of the group, delta, strand, row lane) */
-    /* PACKED: lanes may hold several pieces (gkm_pack.h) and a tile up to MAX_ROWS rows.  When no
-     * lane of the call holds more than one piece (e.g. every fixed-length data set) the leaner
-     * variant runs: one (slot, base) pair per lane, at most 64 rows per tile, 3 KB less LDS
-     * (config 2: 113 ms against 120 ms with the general variant). */
+    /* PACKED: lanes may hold several pieces (gkm_pack.h).  When no lane of the call holds more than one
+     * piece (e.g. every fixed-length data set) the leaner variant runs: one (slot, centre) pair per lane.
+     * The several-pieces variant exists for 64 and for 128 row slots per tile: the profiles of 128 slots
+     * (2.5 KB at d = 4) cost a wave per SIMD, so the host packs at most 64 rows into a tile unless
+     * that would leave lanes empty (many rows shorter than half a lane).  LDS per wave, d = 4, 600 bp:
+     * 3 KB ring + 0.25 KB piece starts + 1 KB piece table + 1.25 KB profiles + 0.6 KB strands and weights
+     * = 6.1 KB -> 6 waves per SIMD (8.4 KB -> 4.75 with 128 slots and two-word piece entries). */
     constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
-    constexpr int NSLOT = PACKED ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
+    constexpr int NSLOT = PK == 2 ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
     __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
-    __shared__ uint32_t lpiece[64 * NP * 2];     /* row slot, centre offset c0 per piece       */
+    /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
+     * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
+    __shared__ uint32_t lpiece[PACKED ? 64 * NP : 128];
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
@@ -499,8 +507,9 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
     }
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
     if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
+    constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
 #pragma unroll
-    for (int k = 0; k < NP * 2; k++) lpiece[lane * NP * 2 + k] = A.lane_piece[(size_t)(tile * 64 + lane) * NP * 2 + k];
+    for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
     const uint32_t lane_tag = (uint32_t)lane << 18;
     const int pkw = A.pkw;
     /* the weight table sits at the start of the dynamic LDS: its address is a constant of the kernel and
@@ -540,8 +549,15 @@ __global__ __launch_bounds__(64, PACKED ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) vo
             const uint32_t r = (ms >> 18) & 63u;
             const uint32_t smask = (uint32_t)((int32_t)(ms << 14) >> 31); /* all ones on the reverse strand (v_bfe_i32) */
             const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], (int)bit) : 0;
-            const uint32_t slot4 = lpiece[(r * NP + k) * 2];    /* row slot * 4 */
-            const uint32_t c0b = lpiece[(r * NP + k) * 2 + 1];  /* (l-mers of the row) / 2 - p0 + b0*W + 2048 */
+            uint32_t slot4, c0b; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
+            if (PACKED) {
+                const uint32_t lp = lpiece[r * NP + k];
+                slot4 = lp & 0xFFFFu;
+                c0b = lp >> 16;
+            } else {
+                slot4 = lpiece[r * 2];
+                c0b = lpiece[r * 2 + 1];
+            }
             const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 63u);
             const uint32_t x = i0 + ((ms >> 6) & 2047u);
             uint32_t q;
@@ -919,7 +935,7 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
 /* ------------------------------------------------- host: launch dispatch */
 typedef void (*bs_kernel_t)(const BsArgs);
 
-template <int W, bool PACKED>
+template <int W, int PACKED>
 static bs_kernel_t pick_bitslice(int L, int d)
 {
 #define GKM_BS(LL, DD) \
@@ -974,7 +990,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
     /* W = 10 words per lane; W = 20 was measured too (config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms):
      * the longer per-shift chain does not pay for the registers it costs */
     bs_kernel_t bs10 = nullptr;
-    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = pick_bitslice<10, true>(L, d);
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = pick_bitslice<10, 2>(L, d);
     if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs10)
         return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
 
@@ -982,28 +998,45 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* pack the rows into lanes at bit-row granularity (gkm_pack.h) */
         std::vector<int> nwin((size_t)nrows);
         for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
-        const gkmpack::Packing pk = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L);
+        /* At most 64 rows per tile unless that leaves lanes empty (rows shorter than half a lane): the
+         * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
+        gkmpack::Packing pk = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, 64);
+        int slots = 64;
+        {
+            gkmpack::Packing wide = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, gkmpack::MAX_ROWS);
+            if (getenv("GKM_FORCE_PACKED") ? !strcmp(getenv("GKM_FORCE_PACKED"), "128")
+                                           : (double)pk.ntiles > 1.04 * (double)wide.ntiles) {
+                pk = std::move(wide);
+                slots = gkmpack::MAX_ROWS;
+            }
+        }
         const int W = pk.W, ntiles = pk.ntiles;
-        /* no lane with a second piece -> the leaner kernel variant (also: at most 64 rows per tile) */
-        bool packed = getenv("GKM_FORCE_PACKED") != nullptr;
+        /* no lane with a second piece -> the leaner kernel variant */
+        bool packed = getenv("GKM_FORCE_PACKED") != nullptr || slots != 64;
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
-        const int NP = packed ? gkmpack::MAX_PIECES : 1;
-        bs_kernel_t bs = packed ? bs10 : pick_bitslice<10, false>(L, d);
+        const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
+        bs_kernel_t bs = !packed ? pick_bitslice<10, 0>(L, d) : slots == 64 ? pick_bitslice<10, 1>(L, d) : bs10;
         if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
-        std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)NP * 2, 0u);
+        std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)LPW, 0u);
         std::vector<int> fill(nl, 0);
         for (const gkmpack::Piece &pc : pk.pieces) {
             const int k = fill[(size_t)pc.lane]++;
             int *dd = &desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
             dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
             lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
-            lane_piece[((size_t)pc.lane * NP + k) * 2] = (uint32_t)pc.slot * 4u; /* byte offset into accl[m][.] */
-            /* the row l-mer at lane position i0 is |c0 - i0| l-mers away from its sequence's centre l-mer;
-             * c0 > -2048, stored with a bias of 2048 so that the kernel's unsigned |a - b| applies */
-            lane_piece[((size_t)pc.lane * NP + k) * 2 + 1] =
-                (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
+            /* byte offset of the row slot in accl[m][.]; the row l-mer at lane position i0 is |c0 - i0| l-mers
+             * away from its sequence's centre l-mer, c0 > -2048 is stored with a bias of 2048 so that the
+             * kernel's unsigned |a - b| applies */
+            const uint32_t slot4 = (uint32_t)pc.slot * 4u;
+            const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
+            if (packed) {
+                lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
+            } else {
+                lane_piece[(size_t)pc.lane * 2] = slot4;
+                lane_piece[(size_t)pc.lane * 2 + 1] = c0b;
+            }
         }
         /* columns [cbeg, cend) per tile */
         std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
@@ -1034,7 +1067,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t o_cbeg = put(cbeg.data(), (size_t)ntiles * sizeof(int));
         const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
         const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
-        const int NS = packed ? gkmpack::MAX_ROWS : 64;
+        const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
         if (scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) || scr.rowpk.ensure(nl * (size_t)rpw) ||
@@ -1072,7 +1105,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             int span = 0;
             for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
             const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / 64)));
-            if (packed)
+            if (slots != 64)
                 hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
                                    A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, out);
             else
@@ -1080,7 +1113,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                                    A.tile_nrows, A.tile_row, A.tile_out, out);
             HIPCHK(hipGetLastError());
         }
-        ctx->last_kernel = packed ? "k_gram_bitslice<packed>" : "k_gram_bitslice";
+        ctx->last_kernel = !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;

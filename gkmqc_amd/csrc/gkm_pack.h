@@ -24,7 +24,7 @@ namespace gkmpack {
 
 constexpr int LANES = 64;
 constexpr int MAX_PIECES = 4;   /* pieces per lane */
-constexpr int MAX_ROWS = 128;   /* row slots per tile */
+constexpr int MAX_ROWS = 128;   /* row slots per tile (a caller may ask pack_rows for fewer) */
 
 struct Piece {
     int32_t lane;  /* global lane index = tile * 64 + lane in tile */
@@ -49,7 +49,7 @@ struct Packing {
 /* rows: ascending sequence indices; nwin[i]: l-mer windows of rows[i] (>= 1).
  * Greedy first-fit in row order (the order matters: a tile only visits columns j <= its largest
  * row, so tiles should hold neighbouring rows). */
-inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L)
+inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows = MAX_ROWS)
 {
     Packing P;
     P.W = W;
@@ -71,7 +71,7 @@ inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int
     };
     for (int i = 0; i < nrows; i++) {
         for (int attempt = 0; attempt < 2; attempt++) {
-            if (tile_rows >= MAX_ROWS) close_tile();
+            if (tile_rows >= max_rows) close_tile();
             open_tile_storage();
             /* remember the cursor so the row can be undone if it does not fit in this tile */
             const size_t mark = P.pieces.size();

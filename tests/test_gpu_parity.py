@@ -267,19 +267,32 @@ def test_every_bitslice_instantiation_against_the_general_kernel(dev, L, d):
         assert (Pa[:14, :14][is_] == want[is_]).all()
 
 
-def test_packed_variant_on_fixed_length_data(dev, monkeypatch):
-    """Fixed-length data normally takes the one-piece-per-lane variant; force the general
-    (several pieces per lane) variant on it as well."""
+def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
+    """Fixed-length data normally takes the one-piece-per-lane variant; force the two several-pieces
+    variants (64 and 128 row slots per tile) on it as well."""
     z = helpers.synthetic_expected()
     seqs = helpers.synth_codes(192, 192, 300)
     il = np.tril_indices(len(seqs))
-    for forced in (False, True):
+    for forced, name in ((None, "k_gram_bitslice"), ("1", "k_gram_bitslice<packed>"), ("128", "k_gram_bitslice<packed,128>")):
         if forced:
-            monkeypatch.setenv("GKM_FORCE_PACKED", "1")
+            monkeypatch.setenv("GKM_FORCE_PACKED", forced)
         res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
-        assert res["kernel"] == ("k_gram_bitslice<packed>" if forced else "k_gram_bitslice")
+        assert res["kernel"] == name
         assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
         assert helpers.max_rel_err(helpers.tril_pack(res["K"].cpu().numpy()), z["c2_cut192_K"]) < K_TOL
+
+
+def test_many_short_rows_take_the_128_slot_variant(dev):
+    """Rows much shorter than a lane: more than 64 of them fit a tile, so the host keeps 128 row slots
+    (capping the tile at 64 rows would leave lanes empty); ragged 150-600 bp rows take the 64-slot variant."""
+    short = helpers.synth_codes(150, 150, 300, (60, 110))
+    a = dev.gram_matrix(short, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    b = dev.gram_matrix(short, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    assert a["kernel"] == "k_gram_bitslice<packed,128>"
+    il = np.tril_indices(len(short))
+    assert (a["P"].cpu().numpy()[il] == b["P"].cpu().numpy()[il]).all()
+    ragged = helpers.synth_codes(100, 100, 300, (150, 600))
+    assert dev.gram_matrix(ragged, 4, 12, 8, 4, kernel=dev.KERNEL_BITSLICE)["kernel"] == "k_gram_bitslice<packed>"
 
 
 def test_tiny_and_degenerate_problems(dev, tmp_path):
