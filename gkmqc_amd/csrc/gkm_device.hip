@@ -166,9 +166,37 @@ struct gkmhip_ctx {
         DevBuf<char> tables;       /* all per-launch tables of the bit-sliced kernel, one upload */
         DevBuf<uint32_t> rowplanes, rowpk;
         DevBuf<double> S;          /* tile-transposed raw values (k_gram_bitslice -> k_untile) */
+        /* host side of `tables`: pinned, so the upload is a true asynchronous copy; `uploaded` says when the
+         * copy engine has finished reading it and the next launch of this slot may overwrite it */
+        char *h_tables = nullptr;
+        size_t h_cap = 0;
+        hipEvent_t uploaded = nullptr;
+        bool upload_pending = false;
+        int host_ensure(size_t bytes)
+        {
+            if (upload_pending) {
+                HIPCHK(hipEventSynchronize(uploaded));
+                upload_pending = false;
+            }
+            if (!uploaded) HIPCHK(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
+            if (bytes <= h_cap) return 0;
+            if (h_tables) (void)hipHostFree(h_tables);
+            h_tables = nullptr;
+            h_cap = 0;
+            HIPCHK(hipHostMalloc((void **)&h_tables, bytes + bytes / 2, hipHostMallocDefault));
+            h_cap = bytes + bytes / 2;
+            return 0;
+        }
         void release()
         {
             rows.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
+            if (upload_pending) (void)hipEventSynchronize(uploaded);
+            upload_pending = false;
+            if (h_tables) (void)hipHostFree(h_tables);
+            h_tables = nullptr;
+            h_cap = 0;
+            if (uploaded) (void)hipEventDestroy(uploaded);
+            uploaded = nullptr;
         }
     } scratch[2];
     int sel = 0;
@@ -882,6 +910,9 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
     if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
     ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
+    /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
+     * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
+    HIPCHK(hipStreamSynchronize(stream));
     ctx->have_lmers = false;
     ctx->have_sb = false;
     ctx->have_colpk = false;
@@ -1070,11 +1101,15 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
-        if (scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) || scr.rowpk.ensure(nl * (size_t)rpw) ||
-            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
+        if (scr.host_ensure(blob.size()) || scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) ||
+            scr.rowpk.ensure(nl * (size_t)rpw) || (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
             return 4;
-        HIPCHK(hipMemcpyAsync(scr.tables.p, blob.data(), blob.size(), hipMemcpyHostToDevice, stream));
-        /* (pageable source: the copy has been staged by the time the call returns) */
+        /* through the slot's pinned buffer: an asynchronous copy from a local (pageable) vector may still be
+         * reading it after this function has returned and freed it */
+        memcpy(scr.h_tables, blob.data(), blob.size());
+        HIPCHK(hipMemcpyAsync(scr.tables.p, scr.h_tables, blob.size(), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(scr.uploaded, stream));
+        scr.upload_pending = true;
         char *tb = scr.tables.p;
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
                            ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
@@ -1118,6 +1153,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
         HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
         DirectArgs A;
         A.rows = ctx->scratch[ctx->sel].rows.p; A.nrows = nrows;
         A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
@@ -1207,6 +1243,7 @@ extern "C" int gkmhip_normalize_rows_full(gkmhip_ctx *ctx, const int *rows, int 
     HIPCHK(hipSetDevice(ctx->device));
     if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
     HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
     hipLaunchKernelGGL(k_normalize_full, dim3((unsigned)((ctx->n + 255) / 256), (unsigned)nrows), dim3(256), 0, stream, G, ld,
                        ctx->scratch[ctx->sel].rows.p, local_rows, ctx->n, sqnorm, ctx->rbf, ctx->gamma);
     HIPCHK(hipGetLastError());

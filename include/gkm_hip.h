@@ -69,7 +69,8 @@ int gkmhip_set_kernel(gkmhip_ctx *ctx, int which);
  * weight of l-mer p of a sequence with n l-mers is wdist[|n/2 - p|] (this is all the
  * reference's exponential-decay weights depend on, src/libgkm.c:912-925); it must cover
  * distances 0..max(n)/2, at most 1024 entries.  wdist == NULL: all weights are 1.
- * Uploads asynchronously on `stream`; device tables are built on first use. */
+ * The upload runs on `stream` and has completed when the call returns (the arrays may be freed);
+ * device tables are built on first use. */
 int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
                          const uint8_t *wdist, int wdist_len, void *stream);
 

@@ -408,3 +408,19 @@ def test_one_process_assembly_through_rccl(dev, monkeypatch):
     with pytest.raises(dev.GkmError):   # RCCL refuses one device twice; the call must fail cleanly, not hang
         dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0, 0])
     dev.load().gkmhip_release_comms()
+
+
+def test_one_process_multi_gpu_assembly_at_full_size(dev):
+    """The configs[3] stand-in (313 tiles, ~2 MB of launch tables per call) through two contexts on one
+    GPU: at this size an asynchronous upload from a local host vector was still in flight when the vector
+    was freed -- the launch tables now travel through a pinned buffer owned by the scratch slot."""
+    import torch
+    from gkmqc_amd import synth
+    seqs = [dev.encode(x) for x in synth.make_peak_sequences(11, 5000, 600, True) +
+            synth.make_peak_sequences(12, 5000, 600, False)]
+    one = dev.gram_matrix(seqs, 4, 10, 6, 3)["K"]
+    for _ in range(2):
+        res = dev.gram_matrix_multi(seqs, 4, 10, 6, 3, devices=[0, 0])
+        for K in res["K"]:
+            assert torch.equal(K, one)
+        del res
