@@ -155,6 +155,6 @@ def test_no_timing_variants_in_the_product(built):
     build_variants/ (tools/variants.sh); the drop-in library must hold VARIANT = 0 instantiations only."""
     import re
     blob = open(os.path.join(ROOT, "gkmqc_amd", "bin", "gkmkern_pylib.so"), "rb").read()
-    names = set(re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELb[01]ELi(\d+)EEv6BsArgs", blob))
-    assert names == {b"0"}, names
+    found = re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELi[012]ELi(\d+)EEv6BsArgs", blob)
+    assert len(found) > 100 and set(found) == {b"0"}, set(found)
     assert b"GKM_VARIANT" not in blob
