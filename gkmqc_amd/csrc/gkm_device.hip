@@ -166,37 +166,53 @@ struct gkmhip_ctx {
         DevBuf<char> tables;       /* all per-launch tables of the bit-sliced kernel, one upload */
         DevBuf<uint32_t> rowplanes, rowpk;
         DevBuf<double> S;          /* tile-transposed raw values (k_gram_bitslice -> k_untile) */
-        /* host side of `tables`: pinned, so the upload is a true asynchronous copy; `uploaded` says when the
-         * copy engine has finished reading it and the next launch of this slot may overwrite it */
-        char *h_tables = nullptr;
-        size_t h_cap = 0;
-        hipEvent_t uploaded = nullptr;
-        bool upload_pending = false;
-        int host_ensure(size_t bytes)
+        /* Host side of the table uploads: pinned buffers, so that the upload is a true asynchronous copy, each
+         * with an event that says when the copy engine has finished reading it.  A pool, not one buffer: the
+         * boundary call enqueues 13 launches up front, and waiting for the previous upload of the slot would
+         * make the host follow the device launch by launch (measured: 81 ms of enqueueing instead of 2, the
+         * copy-out pipeline starting only when the compute was over). */
+        struct HostBuf {
+            char *p = nullptr;
+            size_t cap = 0;
+            hipEvent_t done = nullptr;
+            bool pending = false;
+        };
+        std::vector<HostBuf> pool;
+        HostBuf *host_acquire(size_t bytes)
         {
-            if (upload_pending) {
-                HIPCHK(hipEventSynchronize(uploaded));
-                upload_pending = false;
+            HostBuf *pick = nullptr;
+            for (HostBuf &b : pool) {
+                if (b.pending && hipEventQuery(b.done) == hipSuccess) b.pending = false;
+                if (!b.pending && (!pick || (b.cap >= bytes && pick->cap < bytes))) pick = &b;
             }
-            if (!uploaded) HIPCHK(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming));
-            if (bytes <= h_cap) return 0;
-            if (h_tables) (void)hipHostFree(h_tables);
-            h_tables = nullptr;
-            h_cap = 0;
-            HIPCHK(hipHostMalloc((void **)&h_tables, bytes + bytes / 2, hipHostMallocDefault));
-            h_cap = bytes + bytes / 2;
-            return 0;
+            if (!pick && pool.size() >= 64) { /* bound the pool: wait for the oldest */
+                pick = &pool[0];
+                if (hipEventSynchronize(pick->done) != hipSuccess) return nullptr;
+                pick->pending = false;
+            }
+            if (!pick) {
+                pool.emplace_back();
+                pick = &pool.back();
+                if (hipEventCreateWithFlags(&pick->done, hipEventDisableTiming) != hipSuccess) { pool.pop_back(); return nullptr; }
+            }
+            if (pick->cap < bytes) {
+                if (pick->p) (void)hipHostFree(pick->p);
+                pick->p = nullptr;
+                pick->cap = 0;
+                if (hipHostMalloc((void **)&pick->p, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess) return nullptr;
+                pick->cap = bytes + bytes / 4;
+            }
+            return pick;
         }
         void release()
         {
             rows.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
-            if (upload_pending) (void)hipEventSynchronize(uploaded);
-            upload_pending = false;
-            if (h_tables) (void)hipHostFree(h_tables);
-            h_tables = nullptr;
-            h_cap = 0;
-            if (uploaded) (void)hipEventDestroy(uploaded);
-            uploaded = nullptr;
+            for (HostBuf &b : pool) {
+                if (b.pending) (void)hipEventSynchronize(b.done);
+                if (b.p) (void)hipHostFree(b.p);
+                if (b.done) (void)hipEventDestroy(b.done);
+            }
+            pool.clear();
         }
     } scratch[2];
     int sel = 0;
@@ -1101,15 +1117,17 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
-        if (scr.host_ensure(blob.size()) || scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) ||
-            scr.rowpk.ensure(nl * (size_t)rpw) || (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
+        auto *hb = scr.host_acquire(blob.size());
+        if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
+        if (scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) || scr.rowpk.ensure(nl * (size_t)rpw) ||
+            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
             return 4;
-        /* through the slot's pinned buffer: an asynchronous copy from a local (pageable) vector may still be
+        /* through a pinned buffer of the slot: an asynchronous copy from a local (pageable) vector may still be
          * reading it after this function has returned and freed it */
-        memcpy(scr.h_tables, blob.data(), blob.size());
-        HIPCHK(hipMemcpyAsync(scr.tables.p, scr.h_tables, blob.size(), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipEventRecord(scr.uploaded, stream));
-        scr.upload_pending = true;
+        memcpy(hb->p, blob.data(), blob.size());
+        HIPCHK(hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(hb->done, stream));
+        hb->pending = true;
         char *tb = scr.tables.p;
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
                            ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
