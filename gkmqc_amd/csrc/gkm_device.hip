@@ -104,8 +104,65 @@ static int acquire_staging(size_t want, double **out, int slot)
     return 0;
 }
 
+/* Host side of the per-launch table uploads: a process-wide ring of pinned buffers, so that the upload is a true
+ * asynchronous copy from memory that outlives the call, each buffer with an event that says when the copy
+ * engine has finished reading it.  A ring, not one buffer per context: the boundary call enqueues 13 launches
+ * up front, and waiting for the previous upload would make the host follow the device launch by launch
+ * (measured: 81 ms of enqueueing instead of 2, the copy-out pipeline starting only when the compute was
+ * over).  A buffer comes up for reuse after PIN_RING later uploads; its event is waited for then (a no-op
+ * unless the ring has wrapped inside one call). */
+constexpr size_t PIN_RING = 48;
+struct PinBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    hipEvent_t done = nullptr;
+    int dev = -1;
+    bool pending = false;
+};
+static std::mutex g_pin_mutex;
+static PinBuf g_pin[PIN_RING];
+static size_t g_pin_next = 0;
+
+static PinBuf *pin_acquire(size_t bytes, int device)
+{
+    PinBuf *b;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        b = &g_pin[g_pin_next++ % PIN_RING];
+    }
+    /* (the slot is this caller's until the ring comes round again) */
+    if (b->pending) {
+        if (hipEventSynchronize(b->done) != hipSuccess) return nullptr;
+        b->pending = false;
+    }
+    if (b->dev != device) {
+        if (b->done) (void)hipEventDestroy(b->done);
+        b->done = nullptr;
+        if (hipEventCreateWithFlags(&b->done, hipEventDisableTiming) != hipSuccess) return nullptr;
+        b->dev = device;
+    }
+    if (b->cap < bytes) {
+        if (b->p) (void)hipHostFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc((void **)&b->p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+        b->cap = want;
+    }
+    return b;
+}
+
 extern "C" void gkmhip_release_host_cache(void)
 {
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        for (PinBuf &b : g_pin) {
+            if (b.pending) (void)hipEventSynchronize(b.done);
+            if (b.p) (void)hipHostFree(b.p);
+            if (b.done) (void)hipEventDestroy(b.done);
+            b = PinBuf();
+        }
+    }
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     for (int s = 0; s < STAGE_SLOTS; s++) {
         for (int i = 0; i < 2; i++) {
@@ -121,14 +178,17 @@ template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;
-    int ensure(size_t count)
+    /* headroom: per-launch scratch whose size drifts from launch to launch (the row blocks of the boundary
+     * call) is allocated half as big again, because growing means hipFree, and hipFree waits for the device */
+    int ensure(size_t count, bool headroom = false)
     {
         if (count <= cap) return 0;
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        HIPCHK(hipMalloc((void **)&p, std::max<size_t>(count, 1) * sizeof(T)));
-        cap = count;
+        const size_t want = std::max<size_t>(headroom ? count + count / 2 : count, 1);
+        HIPCHK(hipMalloc((void **)&p, want * sizeof(T)));
+        cap = want;
         return 0;
     }
     void release()
@@ -166,53 +226,9 @@ struct gkmhip_ctx {
         DevBuf<char> tables;       /* all per-launch tables of the bit-sliced kernel, one upload */
         DevBuf<uint32_t> rowplanes, rowpk;
         DevBuf<double> S;          /* tile-transposed raw values (k_gram_bitslice -> k_untile) */
-        /* Host side of the table uploads: pinned buffers, so that the upload is a true asynchronous copy, each
-         * with an event that says when the copy engine has finished reading it.  A pool, not one buffer: the
-         * boundary call enqueues 13 launches up front, and waiting for the previous upload of the slot would
-         * make the host follow the device launch by launch (measured: 81 ms of enqueueing instead of 2, the
-         * copy-out pipeline starting only when the compute was over). */
-        struct HostBuf {
-            char *p = nullptr;
-            size_t cap = 0;
-            hipEvent_t done = nullptr;
-            bool pending = false;
-        };
-        std::vector<HostBuf> pool;
-        HostBuf *host_acquire(size_t bytes)
-        {
-            HostBuf *pick = nullptr;
-            for (HostBuf &b : pool) {
-                if (b.pending && hipEventQuery(b.done) == hipSuccess) b.pending = false;
-                if (!b.pending && (!pick || (b.cap >= bytes && pick->cap < bytes))) pick = &b;
-            }
-            if (!pick && pool.size() >= 64) { /* bound the pool: wait for the oldest */
-                pick = &pool[0];
-                if (hipEventSynchronize(pick->done) != hipSuccess) return nullptr;
-                pick->pending = false;
-            }
-            if (!pick) {
-                pool.emplace_back();
-                pick = &pool.back();
-                if (hipEventCreateWithFlags(&pick->done, hipEventDisableTiming) != hipSuccess) { pool.pop_back(); return nullptr; }
-            }
-            if (pick->cap < bytes) {
-                if (pick->p) (void)hipHostFree(pick->p);
-                pick->p = nullptr;
-                pick->cap = 0;
-                if (hipHostMalloc((void **)&pick->p, bytes + bytes / 4, hipHostMallocDefault) != hipSuccess) return nullptr;
-                pick->cap = bytes + bytes / 4;
-            }
-            return pick;
-        }
         void release()
         {
             rows.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
-            for (HostBuf &b : pool) {
-                if (b.pending) (void)hipEventSynchronize(b.done);
-                if (b.p) (void)hipHostFree(b.p);
-                if (b.done) (void)hipEventDestroy(b.done);
-            }
-            pool.clear();
         }
     } scratch[2];
     int sel = 0;
@@ -1024,6 +1040,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
     if (!ctx || !rows || nrows <= 0) return set_err_msg("gram: bad arguments", 2);
     if (ctx->n <= 0) return set_err_msg("gram: no sequences uploaded", 2);
     HIPCHK(hipSetDevice(ctx->device));
+    (void)hipGetLastError(); /* the launch checks below must see this call's errors only */
     const int L = ctx->L, d = ctx->d, n = ctx->n;
     double comparisons = 0;
     for (int i = 0; i < nrows; i++) {
@@ -1117,13 +1134,14 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
-        auto *hb = scr.host_acquire(blob.size());
+        PinBuf *hb = pin_acquire(blob.size(), ctx->device);
         if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
-        if (scr.tables.ensure(blob.size()) || scr.rowplanes.ensure(nl * 3 * W) || scr.rowpk.ensure(nl * (size_t)rpw) ||
-            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS)))
+        if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) ||
+            scr.rowpk.ensure(nl * (size_t)rpw, true) ||
+            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS, true)))
             return 4;
-        /* through a pinned buffer of the slot: an asynchronous copy from a local (pageable) vector may still be
-         * reading it after this function has returned and freed it */
+        /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
+         * may still be reading it after this function has returned and freed it */
         memcpy(hb->p, blob.data(), blob.size());
         HIPCHK(hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream));
         HIPCHK(hipEventRecord(hb->done, stream));
