@@ -901,6 +901,10 @@ __global__ void k_normalize(double *__restrict__ G, int64_t ld, int r0, const do
 }
 
 /* ---------------------------------------------------------- host: upload */
+static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream);
+static int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream);
+static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream);
+
 extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
                                     const uint8_t *wdist, int wdist_len, void *stream_)
 {
@@ -942,6 +946,12 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
     if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
     ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
+    /* The per-sequence device tables are built HERE, not at the first launch: callers alternate launches between
+     * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
+     * second launch on the other stream before it was complete (found when the host stopped waiting for its
+     * uploads: the config-4 stand-in through two contexts differed in a few hundred rows). */
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream))) return 4;
+    if (ctx->kernel_pref == GKMHIP_KERNEL_DIRECT && ensure_lmers(ctx, stream)) return 4;
     /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
      * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
     HIPCHK(hipStreamSynchronize(stream));
@@ -963,6 +973,7 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
                        ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_lmers = true;
     return 0;
 }
@@ -977,6 +988,7 @@ static int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
                        ctx->colpk.p);
     HIPCHK(hipGetLastError());
     ctx->pkw = pkw;
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_colpk = true;
     return 0;
 }
@@ -991,6 +1003,7 @@ static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
     HIPCHK(hipGetLastError());
     ctx->sb_xw = xw;
     ctx->sb_W = W;
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_sb = true;
     return 0;
 }

@@ -412,8 +412,11 @@ def test_one_process_assembly_through_rccl(dev, monkeypatch):
 
 def test_one_process_multi_gpu_assembly_at_full_size(dev):
     """The configs[3] stand-in (313 tiles, ~2 MB of launch tables per call) through two contexts on one
-    GPU: at this size an asynchronous upload from a local host vector was still in flight when the vector
-    was freed -- the launch tables now travel through a pinned buffer owned by the scratch slot."""
+    GPU, each alternating its launches between two streams.  Two races showed only at this size: an
+    asynchronous upload from a local host vector still in flight when the vector was freed (the launch
+    tables now travel through pinned buffers that outlive the call), and the strand tables built by the
+    first launch on one stream being read by the second launch on the other stream (they are now built,
+    and complete, when the sequences are uploaded)."""
     import torch
     from gkmqc_amd import synth
     seqs = [dev.encode(x) for x in synth.make_peak_sequences(11, 5000, 600, True) +
