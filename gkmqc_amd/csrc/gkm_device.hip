@@ -104,49 +104,45 @@ static int acquire_staging(size_t want, double **out, int slot)
     return 0;
 }
 
-/* Host side of the per-launch table uploads: a process-wide ring of pinned buffers, so that the upload is a true
- * asynchronous copy from memory that outlives the call, each buffer with an event that says when the copy
- * engine has finished reading it.  A ring, not one buffer per context: the boundary call enqueues 13 launches
- * up front, and waiting for the previous upload would make the host follow the device launch by launch
- * (measured: 81 ms of enqueueing instead of 2, the copy-out pipeline starting only when the compute was
- * over).  A buffer comes up for reuse after PIN_RING later uploads; its event is waited for then (a no-op
- * unless the ring has wrapped inside one call). */
-constexpr size_t PIN_RING = 48;
+/* Host side of the per-launch table uploads: a process-wide pool of pinned buffers, so that the upload is a true
+ * asynchronous copy from memory that outlives the call.  A buffer is handed back by a host function enqueued on
+ * the stream right behind the copy (hipLaunchHostFunc: it runs when the copy engine has finished reading), so
+ * no thread ever waits for, or queries, an event of another thread's stream.  A pool, not one buffer per
+ * context: the boundary call enqueues 13 launches up front, and waiting for the previous upload would make the
+ * host follow the device launch by launch (measured: 81 ms of enqueueing instead of 2.5, the copy-out pipeline
+ * starting only when the compute was over). */
 struct PinBuf {
     char *p = nullptr;
     size_t cap = 0;
-    hipEvent_t done = nullptr;
-    int dev = -1;
-    bool pending = false;
+    std::atomic<int> in_use{0};
 };
 static std::mutex g_pin_mutex;
-static PinBuf g_pin[PIN_RING];
-static size_t g_pin_next = 0;
+static std::vector<PinBuf *> g_pin;
 
-static PinBuf *pin_acquire(size_t bytes, int device)
+static void pin_release(void *ud) { ((PinBuf *)ud)->in_use.store(0, std::memory_order_release); }
+
+static PinBuf *pin_acquire(size_t bytes)
 {
-    PinBuf *b;
+    PinBuf *b = nullptr;
     {
         std::lock_guard<std::mutex> lock(g_pin_mutex);
-        b = &g_pin[g_pin_next++ % PIN_RING];
+        for (PinBuf *c : g_pin)
+            if (c->in_use.load(std::memory_order_acquire) == 0 && (!b || (c->cap >= bytes && b->cap < bytes))) b = c;
+        if (!b) {
+            b = new PinBuf();
+            g_pin.push_back(b);
+        }
+        b->in_use.store(1, std::memory_order_relaxed);
     }
-    /* (the slot is this caller's until the ring comes round again) */
-    if (b->pending) {
-        if (hipEventSynchronize(b->done) != hipSuccess) return nullptr;
-        b->pending = false;
-    }
-    if (b->dev != device) {
-        if (b->done) (void)hipEventDestroy(b->done);
-        b->done = nullptr;
-        if (hipEventCreateWithFlags(&b->done, hipEventDisableTiming) != hipSuccess) return nullptr;
-        b->dev = device;
-    }
-    if (b->cap < bytes) {
+    if (b->cap < bytes) { /* (this thread owns b now) */
         if (b->p) (void)hipHostFree(b->p);
         b->p = nullptr;
         b->cap = 0;
         const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
-        if (hipHostMalloc((void **)&b->p, want, hipHostMallocPortable) != hipSuccess) return nullptr;
+        if (hipHostMalloc((void **)&b->p, want, hipHostMallocPortable) != hipSuccess) {
+            b->in_use.store(0);
+            return nullptr;
+        }
         b->cap = want;
     }
     return b;
@@ -156,12 +152,12 @@ extern "C" void gkmhip_release_host_cache(void)
 {
     {
         std::lock_guard<std::mutex> lock(g_pin_mutex);
-        for (PinBuf &b : g_pin) {
-            if (b.pending) (void)hipEventSynchronize(b.done);
-            if (b.p) (void)hipHostFree(b.p);
-            if (b.done) (void)hipEventDestroy(b.done);
-            b = PinBuf();
-        }
+        for (PinBuf *b : g_pin)
+            if (b->in_use.load() == 0 && b->p) {
+                (void)hipHostFree(b->p);
+                b->p = nullptr;
+                b->cap = 0;
+            }
     }
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     for (int s = 0; s < STAGE_SLOTS; s++) {
@@ -1147,7 +1143,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
-        PinBuf *hb = pin_acquire(blob.size(), ctx->device);
+        PinBuf *hb = pin_acquire(blob.size());
         if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
         if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) ||
             scr.rowpk.ensure(nl * (size_t)rpw, true) ||
@@ -1156,9 +1152,16 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
          * may still be reading it after this function has returned and freed it */
         memcpy(hb->p, blob.data(), blob.size());
-        HIPCHK(hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipEventRecord(hb->done, stream));
-        hb->pending = true;
+        {
+            hipError_t ce = hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream);
+            if (ce == hipSuccess && hipLaunchHostFunc(stream, pin_release, hb) != hipSuccess) {
+                ce = hipStreamSynchronize(stream); /* no host function: hand the buffer back once the copy is over */
+                pin_release(hb);
+            } else if (ce != hipSuccess) {
+                pin_release(hb);
+            }
+            HIPCHK(ce);
+        }
         char *tb = scr.tables.p;
         hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4), dim3(64), 0, stream, ctx->codes.p,
                            ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
