@@ -110,7 +110,9 @@ def test_boundary_rejects_bad_input_without_touching_output(dev, tmp_path):
                     posfile=helpers.QUIRK_POS.encode(), negfile=helpers.QUIRK_NEG.encode(), nthreads=1, verbosity=0)
         base.update(kw)
         return dev.gkmOpt(**base)
-    for bad in (opt(L=13), opt(d=5), opt(kernel_type=9), opt(verbosity=7),
+    # k = -1 passes the reference's parameter check (src/gkmkern_pylib.c:38-64 never tests k >= 0); the weights
+    # routine then refuses it, and the call must stop there instead of running on uninitialised weights
+    for bad in (opt(L=13), opt(d=5), opt(kernel_type=9), opt(verbosity=7), opt(k=-1),
                 opt(posfile=str(tmp_path / "nope.fa").encode())):
         rc, kmat, sizes = _call_wrapper(dev, bad)
         assert rc != 0
@@ -158,3 +160,16 @@ def test_no_timing_variants_in_the_product(built):
     found = re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELi[012]ELi(\d+)EEv6BsArgs", blob)
     assert len(found) > 100 and set(found) == {b"0"}, set(found)
     assert b"GKM_VARIANT" not in blob
+
+
+@pytest.mark.parametrize("value", ["0,x", "7,", "-1", "99", "two"])
+def test_device_selection_is_validated(dev, monkeypatch, value):
+    """GKM_DEVICES / GKM_DEVICE that do not name HIP devices of the node are errors, not a silent
+    fallback to device 0 (atoi("x") used to make "0,x" mean device 0 twice)."""
+    for var in ("GKM_DEVICES", "GKM_DEVICE"):
+        monkeypatch.delenv("GKM_DEVICES", raising=False)
+        monkeypatch.delenv("GKM_DEVICE", raising=False)
+        monkeypatch.setenv(var, value)
+        o = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, helpers.QUIRK_POS.encode(), helpers.QUIRK_NEG.encode(), 1, 0)
+        rc, kmat, sizes = _call_wrapper(dev, o)
+        assert rc != 0 and (kmat == -7.0).all() and (sizes == -1).all()
