@@ -430,3 +430,27 @@ def test_one_process_multi_gpu_assembly_at_full_size(dev):
             assert len(rows) == 0, "trial %d copy %d: %d cells in %d rows differ (rows %s .. %s), %d NaN" % (
                 trial, g, int(bad.sum()), len(rows), rows[:8], rows[-4:], int(torch.isnan(K).sum()))
         del res
+
+
+@pytest.mark.parametrize("var,value,ok", [("GKM_DEVICES", "0,x", False), ("GKM_DEVICES", "7,", False), ("GKM_DEVICES", "99", False),
+                                          ("GKM_DEVICE", "-1", False), ("GKM_DEVICE", "two", False), ("GKM_DEVICE", "0", True),
+                                          ("GKM_DEVICES", "1", True), ("GKM_DEVICES", "all", True)])
+def test_device_selection_is_validated(dev, monkeypatch, var, value, ok):
+    """With a GPU present: values that name no device of the node are errors (atoi used to turn "0,x" into
+    device 0 twice), valid ones work, and the caller's current device is left alone."""
+    import torch
+    monkeypatch.delenv("GKM_DEVICES", raising=False)
+    monkeypatch.delenv("GKM_DEVICE", raising=False)
+    monkeypatch.setenv(var, value)
+    n = 45
+    kmat = np.full((n, n), -7.0)
+    rows = (kmat.ctypes.data + np.arange(n) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.full(2, -1, dtype=np.int32)
+    opt = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, helpers.QUIRK_POS.encode(), helpers.QUIRK_NEG.encode(), 1, 0)
+    before = torch.cuda.current_device()
+    rc = dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data)
+    assert torch.cuda.current_device() == before
+    if ok:
+        assert rc == 0 and kmat[n - 1, n - 1] == 1.0
+    else:
+        assert rc != 0 and (kmat == -7.0).all() and (sizes == -1).all()
