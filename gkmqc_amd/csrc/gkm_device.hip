@@ -5,12 +5,13 @@
  * scalar unit (SGPRs), per-wave hit queues in LDS.
  *
  * Kernels
- *   k_pack_lmers      2-bit packed l-mers of both strands (direct kernel input)
  *   k_build_sb        column-strand bit-plane tables, strided layout (gkm_bitslice.h)
- *   k_build_rowplanes row-segment bit planes for one set of rows
- *   k_gram_bitslice   HOT: bit-sliced diagonal mismatch profile -> raw Gram values
- *   k_gram_direct     general fallback: l-mer by l-mer XOR/popcount
- *   k_sqnorm, k_normalize   diagonal square roots, division, RBF, unit diagonal
+ *   k_pack_strands    both strands of every sequence, 16 bases per word (the hit path's column side)
+ *   k_build_rowplanes row-segment bit planes + the lanes' packed positions for one set of rows
+ *   k_gram_bitslice   HOT: bit-sliced diagonal mismatch profile -> raw Gram values, tile-transposed
+ *   k_untile          tile-transposed values -> matrix rows (both sides in 512-byte runs)
+ *   k_pack_lmers, k_gram_direct   general fallback: per-l-mer tables, l-mer by l-mer XOR/popcount
+ *   k_sqnorm, k_normalize, k_assemble_normalize   square roots of the diagonal, division, RBF, unit diagonal
  */
 #include <hip/hip_runtime.h>
 
@@ -485,15 +486,15 @@ constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
 
 /*
- * One wavefront = 64 row segments (one per lane) x a chunk of `cj` column sequences.
- * For every column strand the wave sweeps all T cyclic shifts; per shift each lane
- * evaluates 32*W l-mer window comparisons with ~17 VALU instructions per 32 (gkm_bitslice.h).
+ * One wavefront = 64 row segments (one per lane) x ONE column sequence.
+ * For both strands of the column the wave sweeps all T cyclic shifts; per shift each lane
+ * evaluates 32*W l-mer window comparisons with ~13 VALU instructions per 32 (gkm_bitslice.h).
  * Hit words are parked, compacted over the lanes, in a wave-wide LDS ring of records and turned
  * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
  * control flow besides the push.
  */
 template <int W, int L, int D, int PK, int VARIANT = 0>
-__global__ __launch_bounds__(64, PK ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
      *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile */
