@@ -113,27 +113,33 @@ int fail_with(const std::string &msg, int code)
     return code;
 }
 
-/* all threads of one call meet here; reusable */
+/* All threads of one call meet here; reusable.  wait(flag) returns the OR of the flags the threads brought
+ * to THIS meeting -- the same value in every thread, which is what a decision to enter a collective needs. */
 class HostBarrier {
 public:
     explicit HostBarrier(int n) : n_(n) {}
-    void wait()
+    bool wait(bool flag = false)
     {
         std::unique_lock<std::mutex> lk(m_);
         const int gen = gen_;
+        acc_ = acc_ || flag;
         if (++count_ == n_) {
             count_ = 0;
+            result_ = acc_;
+            acc_ = false;
             gen_++;
             cv_.notify_all();
-        } else {
-            cv_.wait(lk, [&] { return gen != gen_; });
+            return result_;
         }
+        cv_.wait(lk, [&] { return gen != gen_; });
+        return result_;
     }
 
 private:
     std::mutex m_;
     std::condition_variable cv_;
     int n_, count_ = 0, gen_ = 0;
+    bool acc_ = false, result_ = false;
 };
 
 struct Call {
@@ -196,17 +202,21 @@ void rank_thread(Call &C, int g)
                 if (rc && !fail) { fail = true; C.err[(size_t)g] = gkmhip_last_error(); }
             }
             MCHK(hipEventRecord(C.ready[(size_t)g][(size_t)c], st));
-            if (C.use_rccl && !fail) {
+            if (fail) C.failed = 1;
+        }
+        if (C.use_rccl) {
+            /* every rank must enter the collective or none: a rank whose launch failed would leave the others
+             * waiting in the all-gather for ever, so the ranks agree on the host first */
+            if (!C.bar->wait(C.failed.load() != 0)) {
                 MCHK(hipStreamWaitEvent(sc, C.ready[(size_t)g][(size_t)c], 0));
                 const ncclResult_t r = g_rccl.AllGather(my_slab, C.gathered[(size_t)g] + (size_t)c * (size_t)G * slab_elems,
                                                         slab_elems, GKM_NCCL_FLOAT64, g_rccl.comms[(size_t)g], sc);
                 if (r != 0 && !fail) { fail = true; C.err[(size_t)g] = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); }
+                if (fail) C.failed = 1;
             }
-            if (fail) C.failed = 1;
-        }
-        if (!C.use_rccl) {
-            C.bar->wait(); /* every rank has RECORDED ready[.][c]: an unrecorded event would not be waited for */
-            if (!C.failed.load()) {
+        } else {
+            /* every rank has RECORDED ready[.][c]: an unrecorded event would not be waited for */
+            if (!C.bar->wait(C.failed.load() != 0)) {
                 for (int r = 0; r < G && !fail; r++) {
                     MCHK(hipStreamWaitEvent(sc, C.ready[(size_t)r][(size_t)c], 0));
                     MCHK(hipMemcpyPeerAsync(C.gathered[(size_t)g] + ((size_t)c * (size_t)G + (size_t)r) * slab_elems, dev,
