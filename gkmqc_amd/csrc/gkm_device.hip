@@ -1018,15 +1018,15 @@ static bs_kernel_t pick_bitslice(int L, int d)
      * -DGKM_TIMING_VARIANTS): VARIANT != 0 skips parts of the kernel, the results are WRONG.  The
      * product library is built without the macro: no such instantiation, no environment switch
      * (tests/test_host_logic.py::test_no_timing_variants_in_the_product). */
-    if (L == 11 && d == 3) {
+    {
         const char *v = getenv("GKM_VARIANT");
         const int vi = v ? atoi(v) : 0;
-        if (vi == 1) return k_gram_bitslice<W, 11, 3, PACKED, 1>;
-        if (vi == 2) return k_gram_bitslice<W, 11, 3, PACKED, 2>;
-        if (vi == 16) return k_gram_bitslice<W, 11, 3, PACKED, 16>;
-        if (vi == 32) return k_gram_bitslice<W, 11, 3, PACKED, 32>;
-        if (vi == 64) return k_gram_bitslice<W, 11, 3, PACKED, 64>;
-        if (vi == 128) return k_gram_bitslice<W, 11, 3, PACKED, 128>;
+#define GKM_VAR(LL, DD, VV) \
+        if (L == LL && d == DD && vi == VV) return k_gram_bitslice<W, LL, DD, PACKED, VV>;
+#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128)
+        GKM_VARS(11, 3) GKM_VARS(10, 3)
+#undef GKM_VARS
+#undef GKM_VAR
     }
 #endif
     /* every (L, d) the parameter check admits (3 <= L <= 12, d <= min(4, L - 1)), plus (12, 6) for the
