@@ -503,7 +503,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
      * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
      * reads; 32 = records pushed, trips skipped; 64 = multi-hit records dropped after their first hit;
-     * 128 = trips without the LDS accumulate */
+     * 128 = trips without the LDS accumulate; 256 = the resolved hit's whole word cleared by a plain store instead of the LDS xor */
     using namespace gkmbs;
     /* LDS per wave: 3 KB hit ring + 0.5-2.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
      * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
@@ -680,7 +680,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
 #pragma unroll
                         for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
                         *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
-                        atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
+                        if (VARIANT & 256) *(volatile uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)) = 0u; /* timing: plain store, the word is dropped */
+                        else atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
                     }
                     s_n += (int)__popcll(more);
                 }
@@ -1023,7 +1024,7 @@ static bs_kernel_t pick_bitslice(int L, int d)
         const int vi = v ? atoi(v) : 0;
 #define GKM_VAR(LL, DD, VV) \
         if (L == LL && d == DD && vi == VV) return k_gram_bitslice<W, LL, DD, PACKED, VV>;
-#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128)
+#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128) GKM_VAR(LL, DD, 256)
         GKM_VARS(11, 3) GKM_VARS(10, 3)
 #undef GKM_VARS
 #undef GKM_VAR
