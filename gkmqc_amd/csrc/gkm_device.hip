@@ -503,9 +503,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
      * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
      * reads; 32 = records pushed, trips skipped; 64 = multi-hit records dropped after their first hit;
-     * 128 = trips without the LDS accumulate; 256 = the resolved hit's whole word cleared by a plain store instead of the LDS xor */
+     * 128 = trips without the LDS accumulate; 256 = the resolved hit's whole word cleared by a plain store instead of the LDS xor;
+     * 512 = the row lane's packed words read from (arbitrary) LDS instead of global memory: 76.4 vs 77.6 ms on config 2,
+     * 434 vs 454 ms on gkmQC's defaults -- what an LDS-resident copy of the tile's 5.4 KB could gain at best, before paying for it;
+     * 2048 = column words made up by scalar arithmetic instead of scalar loads (what hiding the scalar-load latency could gain) */
     using namespace gkmbs;
-    /* LDS per wave: 3 KB hit ring + 0.5-2.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
+    /* LDS per wave: 3 KB hit ring + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
      * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
      * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
      * of the row lane's packed positions from global memory (5.4 KB per tile, L1 resident: the waves of a CU
@@ -530,7 +533,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
     __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
-    __shared__ uint32_t lpiece[PACKED ? 64 * NP : 128];
+    __shared__ uint32_t lpiece[PACKED ? 64 * NP : 1];
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
@@ -562,11 +565,23 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
         Alo[w] = A.rowplanes[(((size_t)tile * 3 + 1) * W + w) * 64 + lane];
         AV[w] = A.rowplanes[(((size_t)tile * 3 + 2) * W + w) * 64 + lane];
     }
+
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
     if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
     constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
+    if (PACKED) {
 #pragma unroll
-    for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
+        for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
+    }
+    /* one piece per lane: the lane keeps its own (row slot * 4, biased centre offset) in two registers and a
+     * trip fetches the source lane's pair over the DPP/permute network (ds_bpermute_b32: no LDS storage, no
+     * bank conflicts).  The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation
+     * granules of 1 280 (tools/lds_occupancy.hip): 32 instead of 25 one-wave workgroups fit a CU at 600 bp. */
+    uint32_t my_slot4 = 0u, my_c0b = 0u;
+    if (!PACKED) {
+        my_slot4 = A.lane_piece[(size_t)(tile * 64 + lane) * 2];
+        my_c0b = A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1];
+    }
     const uint32_t lane_tag = (uint32_t)lane << 18;
     const int pkw = A.pkw;
     /* the weight table sits at the start of the dynamic LDS: its address is a constant of the kernel and
@@ -600,8 +615,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
          * executes: 24-bit multiply-adds, |a - b| + c as one v_sad_u32, funnel shifts that mask their own shift
          * count, the weight table at a constant LDS offset.  Same arithmetic as resolve_hit_packed
          * (gkm_bitslice.h), which the CPU tests run against the oracle. */
-        auto resolve = [&](uint32_t meta, uint32_t sel, uint32_t bit) {
-            const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 6 bits */
+        auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
             if (VARIANT & 16) { atomicAdd(&accl[rec_lane(ms)], ms | (bit << 24)); return; } /* timing: no table reads */
             const uint32_t r = (ms >> 18) & 63u;
             const uint32_t smask = (uint32_t)((int32_t)(ms << 14) >> 31); /* all ones on the reverse strand (v_bfe_i32) */
@@ -612,8 +626,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
                 slot4 = lp & 0xFFFFu;
                 c0b = lp >> 16;
             } else {
-                slot4 = lpiece[r * 2];
-                c0b = lpiece[r * 2 + 1];
+                slot4 = pslot4;
+                c0b = pc0b;
             }
             const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 63u);
             const uint32_t x = i0 + ((ms >> 6) & 2047u);
@@ -622,7 +636,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
             else q = mod_small(x, (uint32_t)T, rcpT);
             /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
             if ((int)q < nB) {
-                const uint32_t *rw = (const uint32_t *)(rowpk_tile + (__umul24(r, rpw4) + ((i0 >> 2) & ~3u)));
+                const uint32_t *rw = (VARIANT & 512) /* timing: the row words from (arbitrary) LDS instead of global memory */
+                    ? (const uint32_t *)((const char *)s_list + ((__umul24(r, rpw4) + ((i0 >> 2) & ~3u)) & 0x7F8u))
+                    : (const uint32_t *)(rowpk_tile + (__umul24(r, rpw4) + ((i0 >> 2) & ~3u)));
                 const uint32_t *cw = (const uint32_t *)((const char *)s_col + ((smask & pkw4) + ((q >> 2) & ~3u)));
                 const uint8_t *wdb = (const uint8_t *)s_dyn;
                 const uint32_t wa = wdb[__usad(c0b, i0 + 2048u, 0u)];
@@ -667,7 +683,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
 #pragma unroll
                 for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
                 const uint32_t sel = first >> 5, bit = first & 31u;
-                if (total) resolve(meta, sel, bit);
+                const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 6 bits */
+                uint32_t pslot4 = 0u, pc0b = 0u;
+                if (!PACKED) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
+                    const int from = (int)((ms >> 16) & 0xFCu); /* source lane * 4 */
+                    pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
+                    pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
+                }
+                if (total) resolve(ms, bit, pslot4, pc0b);
                 s_hd = (int)ring((uint32_t)(s_hd + c));
                 s_n -= c;
                 const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
@@ -703,6 +726,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
 #pragma unroll
                 for (int i = 0; i < BS_DU + W - 1; i++) {
+                    if (VARIANT & 2048) { /* timing: no scalar loads, the column words are made up (SALU) */
+                        bh[i] = (uint32_t)(d0 + i + j) * 2654435761u;
+                        bl[i] = (uint32_t)(d0 + i + strand) * 2246822519u + (uint32_t)j;
+                        continue;
+                    }
                     bh[i] = sbh[d0 + i];
                     bl[i] = sbl[d0 + i];
                 }
@@ -1024,19 +1052,22 @@ static bs_kernel_t pick_bitslice(int L, int d)
         const int vi = v ? atoi(v) : 0;
 #define GKM_VAR(LL, DD, VV) \
         if (L == LL && d == DD && vi == VV) return k_gram_bitslice<W, LL, DD, PACKED, VV>;
-#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128) GKM_VAR(LL, DD, 256)
+#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128) GKM_VAR(LL, DD, 256) GKM_VAR(LL, DD, 512) GKM_VAR(LL, DD, 2048) GKM_VAR(LL, DD, 2080)
         GKM_VARS(11, 3) GKM_VARS(10, 3)
 #undef GKM_VARS
 #undef GKM_VAR
     }
 #endif
-    /* every (L, d) the parameter check admits (3 <= L <= 12, d <= min(4, L - 1)), plus (12, 6) for the
-     * device layer's own tests */
+    /* every (L, d) with 3 <= L <= 12, d <= min(4, L - 1) (what bin/gkmqc.py:185 can ask for), plus the d > 4 pairs
+     * where this kernel still beats k_gram_direct: a hit costs a whole lane of a trip (~64 lane-instructions), a
+     * comparison 0.45, the general kernel ~5.5 per comparison whatever the hit rate -- break-even at ~8 % of
+     * windows within d mismatches.  iid rates: (12,5) 1.4 %, (11,5) 3.4 %, (12,6) 5.4 %; (10,5) 7.8 %,
+     * (11,6) 11.5 %, (12,7) 15.8 % and everything beyond run faster on the general kernel, which `auto` takes. */
 #define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
     GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
     GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
     GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
-    GKM_BS(12, 6)
+    GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
 #undef GKM_BS_L
 #undef GKM_BS
     return nullptr;
@@ -1414,21 +1445,41 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now();
     double t_wait = 0, t_scatter = 0;
-    hipStream_t sc = nullptr, sd = nullptr;
+    /* The Gram kernels of consecutive blocks alternate between two streams (and the context's two sets of
+     * launch scratch): the waves of block b+1 fill the CUs that the drain of block b leaves idle -- a wave
+     * lives ~0.6 ms and every launch ends with such a tail, 13 of them in a 10 000-row call.  Normalisation
+     * needs the self norms of all earlier rows, so those (tiny) kernels stay in block order on a third
+     * stream, which is also the one the copies wait for. */
+    hipStream_t sg[2] = {nullptr, nullptr}, sc = nullptr, sd = nullptr;
+    HIPCHK(hipStreamCreate(&sg[0]));
+    HIPCHK(hipStreamCreate(&sg[1]));
     HIPCHK(hipStreamCreate(&sc));
     HIPCHK(hipStreamCreate(&sd));
-    std::vector<hipEvent_t> done(B, nullptr);
+    std::vector<hipEvent_t> done(B, nullptr), computed(B, nullptr);
     int rc = 0;
     std::vector<int> idx;
-    if (nparts > 1) rc = gkmhip_self_norms(ctx, ctx->sq.p, sc);
+    const int sel0 = ctx->sel;
+    if (nparts > 1) { /* (that launch uses a set of launch scratch too: the blocks' kernels start after it) */
+        rc = gkmhip_self_norms(ctx, ctx->sq.p, sc);
+        hipEvent_t norms = nullptr;
+        if (!rc && (hipEventCreateWithFlags(&norms, hipEventDisableTiming) != hipSuccess || hipEventRecord(norms, sc) != hipSuccess ||
+                    hipStreamWaitEvent(sg[0], norms, 0) != hipSuccess || hipStreamWaitEvent(sg[1], norms, 0) != hipSuccess))
+            rc = 4;
+        if (norms) (void)hipEventDestroy(norms);
+    }
     for (size_t b = 0; b < B && !rc; b++) { /* enqueue all the compute up front */
         idx.resize((size_t)(blocks[b].r1 - blocks[b].r0));
         for (size_t i = 0; i < idx.size(); i++) idx[i] = blocks[b].r0 + (int)i;
-        rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sc);
+        ctx->sel = (int)(b & 1);
+        rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sg[b & 1]);
+        if (!rc && hipEventCreateWithFlags(&computed[b], hipEventDisableTiming) != hipSuccess) rc = 4;
+        if (!rc && hipEventRecord(computed[b], sg[b & 1]) != hipSuccess) rc = 4;
+        if (!rc && hipStreamWaitEvent(sc, computed[b], 0) != hipSuccess) rc = 4;
         if (!rc) rc = normalize_rows(ctx, G, ld, blocks[b].r0, blocks[b].r1, ctx->sq.p, 0, sc, nparts > 1);
         if (!rc && hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) rc = 4;
         if (!rc && hipEventRecord(done[b], sc) != hipSuccess) rc = 4;
     }
+    ctx->sel = sel0;
     auto issue = [&](size_t b) -> hipError_t {
         const Blk &k = blocks[b];
         hipError_t e = hipStreamWaitEvent(sd, done[b], 0);
@@ -1461,6 +1512,8 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
         }
         t_scatter += now() - ts;
     }
+    (void)hipStreamSynchronize(sg[0]);
+    (void)hipStreamSynchronize(sg[1]);
     (void)hipStreamSynchronize(sc);
     (void)hipStreamSynchronize(sd);
     if (trace)
@@ -1468,6 +1521,10 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
                 B, t_enq - t0, t_wait, t_scatter, now() - t0);
     for (auto ev : done)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto ev : computed)
+        if (ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(sg[0]);
+    (void)hipStreamDestroy(sg[1]);
     (void)hipStreamDestroy(sc);
     (void)hipStreamDestroy(sd);
     if (rc) return rc;
