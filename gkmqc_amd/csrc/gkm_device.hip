@@ -1445,41 +1445,24 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now();
     double t_wait = 0, t_scatter = 0;
-    /* The Gram kernels of consecutive blocks alternate between two streams (and the context's two sets of
-     * launch scratch): the waves of block b+1 fill the CUs that the drain of block b leaves idle -- a wave
-     * lives ~0.6 ms and every launch ends with such a tail, 13 of them in a 10 000-row call.  Normalisation
-     * needs the self norms of all earlier rows, so those (tiny) kernels stay in block order on a third
-     * stream, which is also the one the copies wait for. */
-    hipStream_t sg[2] = {nullptr, nullptr}, sc = nullptr, sd = nullptr;
-    HIPCHK(hipStreamCreate(&sg[0]));
-    HIPCHK(hipStreamCreate(&sg[1]));
+    /* (Alternating the blocks' Gram kernels between two streams, so that block b+1 fills the CUs block b's
+     * drain leaves idle, was measured: 107 instead of 89 ms for the 10 000-row call -- two tiles' worth of
+     * waves on a CU evict each other's packed rows from L1, as with the column-major block order.) */
+    hipStream_t sc = nullptr, sd = nullptr;
     HIPCHK(hipStreamCreate(&sc));
     HIPCHK(hipStreamCreate(&sd));
-    std::vector<hipEvent_t> done(B, nullptr), computed(B, nullptr);
+    std::vector<hipEvent_t> done(B, nullptr);
     int rc = 0;
     std::vector<int> idx;
-    const int sel0 = ctx->sel;
-    if (nparts > 1) { /* (that launch uses a set of launch scratch too: the blocks' kernels start after it) */
-        rc = gkmhip_self_norms(ctx, ctx->sq.p, sc);
-        hipEvent_t norms = nullptr;
-        if (!rc && (hipEventCreateWithFlags(&norms, hipEventDisableTiming) != hipSuccess || hipEventRecord(norms, sc) != hipSuccess ||
-                    hipStreamWaitEvent(sg[0], norms, 0) != hipSuccess || hipStreamWaitEvent(sg[1], norms, 0) != hipSuccess))
-            rc = 4;
-        if (norms) (void)hipEventDestroy(norms);
-    }
+    if (nparts > 1) rc = gkmhip_self_norms(ctx, ctx->sq.p, sc);
     for (size_t b = 0; b < B && !rc; b++) { /* enqueue all the compute up front */
         idx.resize((size_t)(blocks[b].r1 - blocks[b].r0));
         for (size_t i = 0; i < idx.size(); i++) idx[i] = blocks[b].r0 + (int)i;
-        ctx->sel = (int)(b & 1);
-        rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sg[b & 1]);
-        if (!rc && hipEventCreateWithFlags(&computed[b], hipEventDisableTiming) != hipSuccess) rc = 4;
-        if (!rc && hipEventRecord(computed[b], sg[b & 1]) != hipSuccess) rc = 4;
-        if (!rc && hipStreamWaitEvent(sc, computed[b], 0) != hipSuccess) rc = 4;
+        rc = gkmhip_gram_rows(ctx, idx.data(), (int)idx.size(), 0, G, ld, nullptr, 0, sc);
         if (!rc) rc = normalize_rows(ctx, G, ld, blocks[b].r0, blocks[b].r1, ctx->sq.p, 0, sc, nparts > 1);
         if (!rc && hipEventCreateWithFlags(&done[b], hipEventDisableTiming) != hipSuccess) rc = 4;
         if (!rc && hipEventRecord(done[b], sc) != hipSuccess) rc = 4;
     }
-    ctx->sel = sel0;
     auto issue = [&](size_t b) -> hipError_t {
         const Blk &k = blocks[b];
         hipError_t e = hipStreamWaitEvent(sd, done[b], 0);
@@ -1512,8 +1495,6 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
         }
         t_scatter += now() - ts;
     }
-    (void)hipStreamSynchronize(sg[0]);
-    (void)hipStreamSynchronize(sg[1]);
     (void)hipStreamSynchronize(sc);
     (void)hipStreamSynchronize(sd);
     if (trace)
@@ -1521,10 +1502,6 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
                 B, t_enq - t0, t_wait, t_scatter, now() - t0);
     for (auto ev : done)
         if (ev) (void)hipEventDestroy(ev);
-    for (auto ev : computed)
-        if (ev) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(sg[0]);
-    (void)hipStreamDestroy(sg[1]);
     (void)hipStreamDestroy(sc);
     (void)hipStreamDestroy(sd);
     if (rc) return rc;
