@@ -494,11 +494,16 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * control flow besides the push.
  */
 template <int W, int L, int D, int PK, int VARIANT = 0>
-__global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
-     *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile */
-    constexpr bool PACKED = PK != 0;
+     *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
+     *      3: as 0, but a trip fetches the source lane's piece entry from that lane's registers (ds_bpermute_b32)
+     *         instead of a 512-byte table in LDS -- taken when those 512 bytes cost an LDS allocation granule,
+     *         i.e. waves per CU (rows and columns of 600 bp: 25 -> 32 one-wave workgroups per CU, 449 -> 436 ms
+     *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
+    constexpr bool PACKED = PK == 1 || PK == 2;
+    constexpr bool BPERM = PK == 3;
     /* VARIANT (timing experiments only, -DGKM_TIMING_VARIANTS builds, selected by GKM_VARIANT; results are
      * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
      * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
     __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
-    __shared__ uint32_t lpiece[PACKED ? 64 * NP : 1];
+    __shared__ uint32_t lpiece[PACKED ? 64 * NP : BPERM ? 1 : 128];
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
@@ -569,16 +574,16 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
     if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
     constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
-    if (PACKED) {
+    if (!BPERM) {
 #pragma unroll
         for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
     }
-    /* one piece per lane: the lane keeps its own (row slot * 4, biased centre offset) in two registers and a
-     * trip fetches the source lane's pair over the DPP/permute network (ds_bpermute_b32: no LDS storage, no
-     * bank conflicts).  The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation
-     * granules of 1 280 (tools/lds_occupancy.hip): 32 instead of 25 one-wave workgroups fit a CU at 600 bp. */
+    /* BPERM: the lane keeps its own (row slot * 4, biased centre offset) in two registers and a trip fetches
+     * the source lane's pair over the permute network (ds_bpermute_b32: no LDS storage, no bank conflicts).
+     * The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation granules of 1 280
+     * (tools/lds_occupancy.hip): 32 instead of 25 one-wave workgroups fit a CU at 600 bp. */
     uint32_t my_slot4 = 0u, my_c0b = 0u;
-    if (!PACKED) {
+    if (BPERM) {
         my_slot4 = A.lane_piece[(size_t)(tile * 64 + lane) * 2];
         my_c0b = A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1];
     }
@@ -625,9 +630,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
                 const uint32_t lp = lpiece[r * NP + k];
                 slot4 = lp & 0xFFFFu;
                 c0b = lp >> 16;
-            } else {
+            } else if (BPERM) {
                 slot4 = pslot4;
                 c0b = pc0b;
+            } else {
+                slot4 = lpiece[r * 2];
+                c0b = lpiece[r * 2 + 1];
             }
             const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 63u);
             const uint32_t x = i0 + ((ms >> 6) & 2047u);
@@ -685,7 +693,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK ? GKM_BS_PACKED_WAVES : GKM_BS_W
                 const uint32_t sel = first >> 5, bit = first & 31u;
                 const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 6 bits */
                 uint32_t pslot4 = 0u, pc0b = 0u;
-                if (!PACKED) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
+                if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
                     const int from = (int)((ms >> 16) & 0xFCu); /* source lane * 4 */
                     pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
                     pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
@@ -1122,6 +1130,18 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
         const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
         bs_kernel_t bs = !packed ? pick_bitslice<10, 0>(L, d) : slots == 64 ? pick_bitslice<10, 1>(L, d) : bs10;
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t);
+        bool bperm = false;
+        if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
+            hipFuncAttributes fa;
+            const char *force = getenv("GKM_FORCE_BPERM");
+            auto granules = [](size_t bytes) { return (bytes + 1279) / 1280; };
+            if (force ? atoi(force) != 0
+                      : (hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess &&
+                         granules(fa.sharedSizeBytes + dyn_lds) > granules(fa.sharedSizeBytes - 508 + dyn_lds)))
+                bperm = true;
+            if (bperm) bs = pick_bitslice<10, 3>(L, d);
+        }
         if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
@@ -1211,7 +1231,6 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
         A.ntiles = ntiles;
-        const size_t dyn_lds = (size_t)(2 * A.pkw + A.wd_words) * sizeof(uint32_t);
         A.S = out.G ? scr.S.p : nullptr;
         A.tile_soff = (const int64_t *)(tb + o_soff);
         /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
@@ -1233,7 +1252,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                                    A.tile_nrows, A.tile_row, A.tile_out, out);
             HIPCHK(hipGetLastError());
         }
-        ctx->last_kernel = !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+        ctx->last_kernel = bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;

@@ -282,6 +282,31 @@ def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
         assert helpers.max_rel_err(helpers.tril_pack(res["K"].cpu().numpy()), z["c2_cut192_K"]) < K_TOL
 
 
+def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
+    """One piece per lane: the trip reads the source lane's piece entry from a 512-byte LDS table, or from that
+    lane's registers (ds_bpermute) where the table would cost an LDS allocation granule (long sequences).  Both
+    variants, forced either way, on 300-bp rows (one lane each) and 600-bp rows (two lanes each)."""
+    z = helpers.synthetic_expected()
+    seqs = helpers.synth_codes(192, 192, 300)
+    il = np.tril_indices(len(seqs))
+    assert dev.gram_matrix(seqs, 4, 11, 7, 3, kernel=dev.KERNEL_BITSLICE)["kernel"] == "k_gram_bitslice"
+    long_rows = helpers.synth_codes(70, 70, 600)
+    want = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    auto = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    assert auto["kernel"] == "k_gram_bitslice<bperm>"
+    il2 = np.tril_indices(len(long_rows))
+    assert (auto["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
+    for forced, name in (("1", "k_gram_bitslice<bperm>"), ("0", "k_gram_bitslice")):
+        monkeypatch.setenv("GKM_FORCE_BPERM", forced)
+        res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        assert res["kernel"] == name
+        assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
+        res = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        assert res["kernel"] == name
+        assert (res["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
+        assert (res["K"].cpu().numpy() == want["K"].cpu().numpy()).all()
+
+
 def test_many_short_rows_take_the_128_slot_variant(dev):
     """Rows much shorter than a lane: more than 64 of them fit a tile, so the host keeps 128 row slots
     (capping the tile at 64 rows would leave lanes empty); ragged 150-600 bp rows take the 64-slot variant."""
