@@ -441,6 +441,395 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     }
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * The general solver: LIBSVM's Solver::Solve as written (sklearn/svm/src/libsvm/svm.cpp), WITH the
+ * shrinking heuristic (`--shrinking 1`, reference scripts/gkmsvm.py:110-118 passes it through to SVC)
+ * and without the 16 384-sample limit of k_smo.  State lives in global memory (L2-resident: 45 bytes per
+ * sample), one workgroup of 1024 threads per fold, positions dealt to the threads round-robin.
+ *
+ * Shrinking permutes the problem (Solver::swap_index), and LIBSVM's selections scan positions in
+ * order and keep the LAST of equal candidates -- so the permutation has to be LIBSVM's own:
+ *   do_shrinking   Gmax1/Gmax2 by block reductions (a maximum has no order), be_shrunk() of every
+ *                  active position in parallel, then ONE thread walks LIBSVM's two-pointer loop over
+ *                  those flags (in LDS) and writes down the swaps, which all threads apply;
+ *   reconstruct_gradient   for an inactive sample the sum over the free active samples runs in
+ *                  ascending position in both of LIBSVM's loop orders: one thread per inactive
+ *                  sample adds them in that order (list of free samples built in position order);
+ *   G_bar          updated for all l samples whenever alpha_i or alpha_j reaches or leaves C.
+ * Every floating-point expression is LIBSVM's (Qfloat rounding, operation order; -ffp-contract=off).
+ * With shrinking = 0 the same kernel is the no-shrinking solver for folds that k_smo cannot hold.
+ */
+struct GenProb {
+    const int *idx;
+    int l, n0;
+    double *alpha_out, *grad_out, *rho;
+    int *iters;
+    /* scratch, l entries each (device) */
+    int *gidx, *ys, *aset, *swaps; /* swaps: 2 ints per entry */
+    double *alpha, *G, *Gbar, *QD, *fa; /* fa: alpha of the free active samples, in position order */
+    int *fg, *fy;                       /* their matrix index and label */
+    float *Qi, *Qj;
+};
+
+constexpr int GEN_T = 1024;
+constexpr int GEN_NW = GEN_T / 64;
+
+struct GenSel {
+    double v;
+    int k;
+};
+
+/* block-wide best (value, position) with LIBSVM's tie rule; every thread returns the same pair */
+template <bool MINIMISE>
+__device__ __forceinline__ void block_select(double &v, int &k, GenSel *slots)
+{
+    wave_select<MINIMISE>(v, k);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads(); /* the previous use of `slots` has been read */
+    if (lane == 0) { slots[wave].v = v; slots[wave].k = k; }
+    __syncthreads();
+    double bv = MINIMISE ? INFINITY : -INFINITY;
+    int bk = -1;
+#pragma unroll
+    for (int w = 0; w < GEN_NW; w++)
+        if (better<MINIMISE>(slots[w].v, slots[w].k, bv, bk)) { bv = slots[w].v; bk = slots[w].k; }
+    v = bv;
+    k = bk;
+}
+__device__ __forceinline__ double block_max(double v, double *slots)
+{
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) slots[wave] = v;
+    __syncthreads();
+    double m = slots[0];
+#pragma unroll
+    for (int w = 1; w < GEN_NW; w++) m = fmax(m, slots[w]);
+    return m;
+}
+
+__global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict__ K, int64_t ld,
+                                                       const double *__restrict__ diag, const GenProb *probs, double C,
+                                                       double eps, int max_iter, int shrinking)
+{
+    __shared__ GenSel sel_s[GEN_NW];
+    __shared__ double max_s[GEN_NW];
+    __shared__ double chunk[GEN_T];
+    __shared__ int chunk_g[GEN_T], chunk_y[GEN_T];
+    __shared__ int misc[4];
+    extern __shared__ unsigned char flag_s[]; /* l bytes: be_shrunk() of every active position */
+    const GenProb p = probs[blockIdx.x];
+    const int tid = threadIdx.x, l = p.l;
+    int *const gidx = p.gidx, *const ys = p.ys, *const aset = p.aset;
+    double *const alpha = p.alpha, *const G = p.G, *const Gbar = p.Gbar, *const QD = p.QD;
+    float *const Qi = p.Qi, *const Qj = p.Qj;
+
+    for (int k = tid; k < l; k += GEN_T) {
+        const int g = p.idx[k];
+        gidx[k] = g;
+        ys[k] = k < p.n0 ? 1 : -1;
+        aset[k] = k;
+        alpha[k] = 0.0;
+        G[k] = -1.0; /* p = -1 */
+        Gbar[k] = 0.0;
+        QD[k] = diag[g];
+    }
+    __syncthreads();
+
+    auto is_upper = [&](double a) { return a >= C; };
+    auto is_lower = [&](double a) { return a <= 0.0; };
+    /* Q_t[k] = (Qfloat)(y_t y_k K_tk) for k in [k0, k1) */
+    auto q_row = [&](int t, float *out, int k0, int k1) {
+        const double *Kt = K + (int64_t)gidx[t] * ld;
+        const int yt = ys[t];
+        for (int k = k0 + tid; k < k1; k += GEN_T) out[k] = (float)((double)(yt * ys[k]) * Kt[gidx[k]]);
+    };
+
+    int active = l;
+    /* Solver::reconstruct_gradient */
+    auto reconstruct = [&]() {
+        if (active == l) return;
+        /* the free active samples, in position order (thread 0 appends, a block of positions at a time) */
+        __syncthreads();
+        if (tid == 0) misc[0] = 0;
+        for (int k0 = 0; k0 < active; k0 += GEN_T) {
+            const int k = k0 + tid;
+            const double a = k < active ? alpha[k] : 0.0;
+            __syncthreads();
+            chunk[tid] = (k < active && !is_upper(a) && !is_lower(a)) ? a : -1.0;
+            chunk_g[tid] = k < active ? gidx[k] : 0;
+            chunk_y[tid] = k < active ? ys[k] : 0;
+            __syncthreads();
+            if (tid == 0) {
+                int nf = misc[0];
+                const int m = active - k0 < GEN_T ? active - k0 : GEN_T;
+                for (int t = 0; t < m; t++)
+                    if (chunk[t] >= 0.0) { p.fa[nf] = chunk[t]; p.fg[nf] = chunk_g[t]; p.fy[nf] = chunk_y[t]; nf++; }
+                misc[0] = nf;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int nf = misc[0];
+        for (int j = active + tid; j < l; j += GEN_T) {
+            double g = Gbar[j] + (-1.0);
+            const int gj = gidx[j], yj = ys[j];
+            for (int f0 = 0; f0 < nf; f0 += 8) { /* 8 kernel values in flight, the additions in order */
+                double kv[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) kv[u] = K[(int64_t)p.fg[f0 + u < nf ? f0 + u : nf - 1] * ld + gj];
+#pragma unroll
+                for (int u = 0; u < 8; u++)
+                    if (f0 + u < nf) g += p.fa[f0 + u] * (double)(float)((double)(p.fy[f0 + u] * yj) * kv[u]);
+            }
+            G[j] = g;
+        }
+        __syncthreads();
+    };
+
+    /* Solver::select_working_set; 0 = pair found.  Leaves Q_i[0..active) in Qi. */
+    double Gmax = 0.0;
+    auto select = [&](int &out_i, int &out_j) -> int {
+        double gm = -INFINITY;
+        int gi = -1;
+        for (int k = tid; k < active; k += GEN_T) {
+            const double a = alpha[k], g = G[k];
+            if (ys[k] == +1) {
+                if (!is_upper(a) && -g >= gm) { gm = -g; gi = k; }
+            } else {
+                if (!is_lower(a) && g >= gm) { gm = g; gi = k; }
+            }
+        }
+        block_select<false>(gm, gi, sel_s);
+        const int i = gi;
+        Gmax = gm;
+        if (i < 0) return 1;
+        q_row(i, Qi, 0, active);
+        const double QDi = QD[i];
+        const double yi2 = 2.0 * (double)ys[i];
+        double gm2 = -INFINITY, omin = INFINITY;
+        int gj = -1;
+        for (int k = tid; k < active; k += GEN_T) { /* (each thread reads back the Q_i entries it wrote) */
+            const double a = alpha[k], g = G[k];
+            if (ys[k] == +1) {
+                if (!is_lower(a)) {
+                    const double grad_diff = gm + g;
+                    if (g >= gm2) gm2 = g;
+                    if (grad_diff > 0) {
+                        const double quad_coef = QDi + QD[k] - yi2 * (double)Qi[k];
+                        const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
+                        if (obj_diff <= omin) { gj = k; omin = obj_diff; }
+                    }
+                }
+            } else {
+                if (!is_upper(a)) {
+                    const double grad_diff = gm - g;
+                    if (-g >= gm2) gm2 = -g;
+                    if (grad_diff > 0) {
+                        const double quad_coef = QDi + QD[k] + yi2 * (double)Qi[k];
+                        const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
+                        if (obj_diff <= omin) { gj = k; omin = obj_diff; }
+                    }
+                }
+            }
+        }
+        const double Gmax2 = block_max(gm2, max_s);
+        block_select<true>(omin, gj, sel_s);
+        if (gm + Gmax2 < eps || gj < 0) return 1;
+        out_i = i;
+        out_j = gj;
+        return 0;
+    };
+
+    /* Solver::do_shrinking */
+    bool unshrink = false;
+    auto do_shrinking = [&]() {
+        double g1 = -INFINITY, g2 = -INFINITY;
+        for (int k = tid; k < active; k += GEN_T) {
+            const double a = alpha[k], g = G[k];
+            if (ys[k] == +1) {
+                if (!is_upper(a) && -g >= g1) g1 = -g;
+                if (!is_lower(a) && g >= g2) g2 = g;
+            } else {
+                if (!is_upper(a) && -g >= g2) g2 = -g;
+                if (!is_lower(a) && g >= g1) g1 = g;
+            }
+        }
+        const double Gmax1 = block_max(g1, max_s), Gmax2 = block_max(g2, max_s);
+        if (!unshrink && Gmax1 + Gmax2 <= eps * 10) {
+            unshrink = true;
+            reconstruct();
+            active = l;
+        }
+        __syncthreads();
+        for (int k = tid; k < active; k += GEN_T) {
+            const double a = alpha[k], g = G[k];
+            bool sh = false;
+            if (is_upper(a)) sh = ys[k] == +1 ? -g > Gmax1 : -g > Gmax2;
+            else if (is_lower(a)) sh = ys[k] == +1 ? g > Gmax2 : g > Gmax1;
+            flag_s[k] = sh ? 1 : 0;
+        }
+        __syncthreads();
+        if (tid == 0) { /* LIBSVM's loop, on the flags; a swap exchanges the flags too */
+            int as = active, ns = 0;
+            for (int i = 0; i < as; i++)
+                if (flag_s[i]) {
+                    as--;
+                    while (as > i) {
+                        if (!flag_s[as]) {
+                            p.swaps[2 * ns] = i; p.swaps[2 * ns + 1] = as; ns++;
+                            flag_s[i] = 0; flag_s[as] = 1;
+                            break;
+                        }
+                        as--;
+                    }
+                }
+            misc[1] = as;
+            misc[2] = ns;
+        }
+        __threadfence_block();
+        __syncthreads();
+        active = misc[1];
+        const int ns = misc[2];
+        for (int s = tid; s < ns; s += GEN_T) { /* Solver::swap_index: the pairs are disjoint */
+            const int a = p.swaps[2 * s], b = p.swaps[2 * s + 1];
+            { const int t = gidx[a]; gidx[a] = gidx[b]; gidx[b] = t; }
+            { const int t = ys[a]; ys[a] = ys[b]; ys[b] = t; }
+            { const int t = aset[a]; aset[a] = aset[b]; aset[b] = t; }
+            { const double t = alpha[a]; alpha[a] = alpha[b]; alpha[b] = t; }
+            { const double t = G[a]; G[a] = G[b]; G[b] = t; }
+            { const double t = Gbar[a]; Gbar[a] = Gbar[b]; Gbar[b] = t; }
+            { const double t = QD[a]; QD[a] = QD[b]; QD[b] = t; }
+        }
+        __syncthreads();
+    };
+
+    int iter = 0;
+    int counter = (l < 1000 ? l : 1000) + 1;
+    for (;;) {
+        if (iter >= max_iter) {
+            if (active < l) { reconstruct(); active = l; }
+            iter = -iter;
+            break;
+        }
+        if (--counter == 0) {
+            counter = l < 1000 ? l : 1000;
+            if (shrinking) do_shrinking();
+        }
+        int i = -1, j = -1;
+        if (select(i, j) != 0) {
+            reconstruct();
+            active = l;
+            if (select(i, j) != 0) break;
+            counter = 1; /* do shrinking next iteration */
+        }
+        ++iter;
+        /* the two-variable update: every thread computes the same scalars */
+        q_row(j, Qj, 0, active);
+        __syncthreads(); /* Qi[j] (written by another thread in select) and Qj are visible */
+        const int yi = ys[i], yj = ys[j];
+        const double old_ai = alpha[i], old_aj = alpha[j];
+        double ai = old_ai, aj = old_aj;
+        const double Qij = (double)Qi[j];
+        if (yi != yj) {
+            double quad_coef = QD[i] + QD[j] + 2 * Qij;
+            if (quad_coef <= 0) quad_coef = SVM_TAU;
+            const double delta = (-G[i] - G[j]) / quad_coef;
+            const double diff = ai - aj;
+            ai += delta;
+            aj += delta;
+            if (diff > 0) {
+                if (aj < 0) { aj = 0; ai = diff; }
+            } else {
+                if (ai < 0) { ai = 0; aj = -diff; }
+            }
+            if (diff > C - C) {
+                if (ai > C) { ai = C; aj = C - diff; }
+            } else {
+                if (aj > C) { aj = C; ai = C + diff; }
+            }
+        } else {
+            double quad_coef = QD[i] + QD[j] - 2 * Qij;
+            if (quad_coef <= 0) quad_coef = SVM_TAU;
+            const double delta = (G[i] - G[j]) / quad_coef;
+            const double sum = ai + aj;
+            ai -= delta;
+            aj += delta;
+            if (sum > C) {
+                if (ai > C) { ai = C; aj = sum - C; }
+            } else {
+                if (aj < 0) { aj = 0; ai = sum; }
+            }
+            if (sum > C) {
+                if (aj > C) { aj = C; ai = sum - C; }
+            } else {
+                if (ai < 0) { ai = 0; aj = sum; }
+            }
+        }
+        const double dai = ai - old_ai, daj = aj - old_aj;
+        __syncthreads(); /* everybody has read G[i], G[j], alpha[i], alpha[j] */
+        for (int k = tid; k < active; k += GEN_T) G[k] += (double)Qi[k] * dai + (double)Qj[k] * daj;
+        if (tid == 0) { alpha[i] = ai; alpha[j] = aj; }
+        if (shrinking) { /* G_bar only matters to reconstruct_gradient */
+            const bool ui = is_upper(old_ai), uj = is_upper(old_aj);
+            if (ui != is_upper(ai)) {
+                __syncthreads();
+                q_row(i, Qi, 0, l);
+                for (int k = tid; k < l; k += GEN_T) Gbar[k] = ui ? Gbar[k] - C * (double)Qi[k] : Gbar[k] + C * (double)Qi[k];
+            }
+            if (uj != is_upper(aj)) {
+                __syncthreads();
+                q_row(j, Qj, 0, l);
+                for (int k = tid; k < l; k += GEN_T) Gbar[k] = uj ? Gbar[k] - C * (double)Qj[k] : Gbar[k] + C * (double)Qj[k];
+            }
+        }
+        __syncthreads();
+    }
+
+    /* Solver::calculate_rho over all l positions (active == l here), the free samples summed in position order */
+    __syncthreads();
+    int nr_free = 0;
+    double ub = INFINITY, lb = -INFINITY, sum_free = 0;
+    for (int k0 = 0; k0 < l; k0 += GEN_T) {
+        const int k = k0 + tid;
+        bool is_free = false;
+        double yG = 0;
+        if (k < l) {
+            const double a = alpha[k];
+            yG = (double)ys[k] * G[k];
+            if (is_upper(a)) {
+                if (ys[k] == -1) ub = fmin(ub, yG); else lb = fmax(lb, yG);
+            } else if (is_lower(a)) {
+                if (ys[k] == +1) ub = fmin(ub, yG); else lb = fmax(lb, yG);
+            } else {
+                is_free = true;
+            }
+        }
+        __syncthreads();
+        chunk[tid] = is_free ? yG : NAN;
+        __syncthreads();
+        if (tid == 0) {
+            const int m = l - k0 < GEN_T ? l - k0 : GEN_T;
+            for (int t = 0; t < m; t++) {
+                const double x = chunk[t];
+                if (x == x) { ++nr_free; sum_free += x; }
+            }
+        }
+    }
+    ub = -block_max(-ub, max_s);
+    lb = block_max(lb, max_s);
+    if (tid == 0) {
+        *p.rho = nr_free > 0 ? sum_free / nr_free : (ub + lb) / 2;
+        *p.iters = iter;
+    }
+    for (int k = tid; k < l; k += GEN_T) { /* put back the solution */
+        p.alpha_out[aset[k]] = alpha[k];
+        p.grad_out[aset[k]] = G[k];
+    }
+}
+
 struct DecProb {
     const int *idx;
     int l, n0;
@@ -555,6 +944,72 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     (void)hipFree(diag);
     (void)hipFree(dprobs);
     if (e != hipSuccess) return svm_fail("k_smo", e);
+    return 0;
+}
+
+constexpr int GEN_MAX_L = 60000; /* one byte of LDS per sample for the shrinking flags */
+
+extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t ld, int n, int nprob, const int *idx,
+                                          const int64_t *off, const int *n0, double C, double eps, int shrinking,
+                                          double *alpha, double *grad, double *rho, int *iters, void *stream_)
+{
+    if (!K || n <= 0 || ld < n || nprob <= 0 || !idx || !off || !n0 || !alpha || !grad || !rho || !iters) {
+        g_svm_err = "gkmsvm_train_batch_general: bad arguments";
+        return 2;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    SVMCHK(hipSetDevice(device));
+    const int64_t total = off[nprob];
+    int64_t maxl = 0;
+    for (int p = 0; p < nprob; p++) {
+        const int64_t l = off[p + 1] - off[p];
+        if (l > maxl) maxl = l;
+        if (l <= 0 || l > (int64_t)GEN_MAX_L || n0[p] < 0 || n0[p] > l) {
+            g_svm_err = "gkmsvm_train_batch_general: a problem has no samples or more than 60000";
+            return 3;
+        }
+    }
+    /* scratch: 6 int, 5 double, 2 float arrays of `total` entries */
+    char *scratch = nullptr;
+    const size_t per = 6 * sizeof(int) + 5 * sizeof(double) + 2 * sizeof(float);
+    SVMCHK(hipMalloc((void **)&scratch, per * (size_t)total + 64));
+    double *d0 = (double *)scratch;
+    int *i0 = (int *)(d0 + 5 * total);
+    float *f0 = (float *)(i0 + 6 * total);
+    std::vector<GenProb> h((size_t)nprob);
+    for (int p = 0; p < nprob; p++) {
+        const int64_t o = off[p];
+        GenProb &g = h[(size_t)p];
+        g.idx = idx + o; g.l = (int)(off[p + 1] - o); g.n0 = n0[p];
+        g.alpha_out = alpha + o; g.grad_out = grad + o; g.rho = rho + p; g.iters = iters + p;
+        g.alpha = d0 + o; g.G = d0 + total + o; g.Gbar = d0 + 2 * total + o; g.QD = d0 + 3 * total + o; g.fa = d0 + 4 * total + o;
+        g.gidx = i0 + o; g.ys = i0 + total + o; g.aset = i0 + 2 * total + o; g.swaps = i0 + 3 * total + o;
+        g.fg = i0 + 4 * total + o; g.fy = i0 + 5 * total + o;
+        g.Qi = f0 + o; g.Qj = f0 + total + o;
+    }
+    GenProb *dprobs = nullptr;
+    double *diag = nullptr;
+    hipError_t e = hipMalloc((void **)&dprobs, sizeof(GenProb) * (size_t)nprob);
+    if (e == hipSuccess) e = hipMalloc((void **)&diag, sizeof(double) * (size_t)n);
+    if (e == hipSuccess) e = hipMemcpyAsync(dprobs, h.data(), sizeof(GenProb) * (size_t)nprob, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream); /* h is a host temporary */
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
+        int max_iter = 10000000;
+        if (const char *mi = getenv("GKM_SVM_MAX_ITER")) if (atoi(mi) > 0) max_iter = atoi(mi);
+        const size_t dyn = ((size_t)maxl + 15) & ~(size_t)15;
+        e = hipFuncSetAttribute((const void *)k_smo_general, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_smo_general, dim3((unsigned)nprob), dim3(GEN_T), dyn, stream, K, ld, diag, dprobs, C, eps,
+                               max_iter, shrinking ? 1 : 0);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    }
+    (void)hipFree(diag);
+    (void)hipFree(dprobs);
+    (void)hipFree(scratch);
+    if (e != hipSuccess) return svm_fail("k_smo_general", e);
     return 0;
 }
 

@@ -19,7 +19,8 @@ import numpy as np
 from . import device
 
 
-MAX_FOLD_SAMPLES = 16384   # one workgroup per fold: 1024 threads x 16 samples (gkm_svm.hip)
+FAST_FOLD_SAMPLES = 16384  # k_smo: one workgroup per fold, 1024 threads x 16 samples in registers (gkm_svm.hip)
+MAX_FOLD_SAMPLES = 60000   # k_smo_general: state in global memory, also the solver with LIBSVM's shrinking
 
 
 class SvmError(RuntimeError):
@@ -32,6 +33,8 @@ def _lib():
         vp, i32, i64, dbl = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double
         L.gkmsvm_train_batch.restype = i32
         L.gkmsvm_train_batch.argtypes = (i32, vp, i64, i32, i32, vp, vp, vp, dbl, dbl, vp, vp, vp, vp, vp)
+        L.gkmsvm_train_batch_general.restype = i32
+        L.gkmsvm_train_batch_general.argtypes = (i32, vp, i64, i32, i32, vp, vp, vp, dbl, dbl, i32, vp, vp, vp, vp, vp)
         L.gkmsvm_decision_batch.restype = i32
         L.gkmsvm_decision_batch.argtypes = (i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
         L.gkmsvm_last_error.restype = ctypes.c_char_p
@@ -66,9 +69,11 @@ class FoldSolutions:
         return -(a[sv] * ysign[sv]), self.idx[f][sv]
 
 
-def train_folds(K, trains, y, C=1.0, tol=1e-3):
+def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False):
     """Solve one C-SVC per entry of `trains` (index arrays into the symmetric torch CUDA fp64
-    matrix K) concurrently.  Returns (FoldSolutions, device handles for `decision_values`)."""
+    matrix K) concurrently.  Returns (FoldSolutions, device handles for `decision_values`).
+    `shrinking`: LIBSVM's shrinking heuristic (scikit-learn `SVC(shrinking=True)`); it and folds of more
+    than 16 384 samples run on the general solver (k_smo_general), everything else on k_smo."""
     import torch
     if not (K.is_cuda and K.dtype == torch.float64 and K.dim() == 2 and K.shape[0] == K.shape[1]
             and K.stride(1) == 1):
@@ -87,9 +92,15 @@ def train_folds(K, trains, y, C=1.0, tol=1e-3):
         d_grad = torch.empty_like(d_alpha)
         d_rho = torch.empty(len(idx), dtype=torch.float64, device=dev)
         d_it = torch.empty(len(idx), dtype=torch.int32, device=dev)
-        rc = L.gkmsvm_train_batch(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx), d_idx.data_ptr(),
-                                  off.ctypes.data, n0.ctypes.data, float(C), float(tol), d_alpha.data_ptr(),
-                                  d_grad.data_ptr(), d_rho.data_ptr(), d_it.data_ptr(), stream)
+        if shrinking or max(len(i) for i in idx) > FAST_FOLD_SAMPLES:
+            rc = L.gkmsvm_train_batch_general(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx),
+                                              d_idx.data_ptr(), off.ctypes.data, n0.ctypes.data, float(C), float(tol),
+                                              1 if shrinking else 0, d_alpha.data_ptr(), d_grad.data_ptr(),
+                                              d_rho.data_ptr(), d_it.data_ptr(), stream)
+        else:
+            rc = L.gkmsvm_train_batch(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx), d_idx.data_ptr(),
+                                      off.ctypes.data, n0.ctypes.data, float(C), float(tol), d_alpha.data_ptr(),
+                                      d_grad.data_ptr(), d_rho.data_ptr(), d_it.data_ptr(), stream)
         if rc:
             raise SvmError("gkmsvm_train_batch: %s" % L.gkmsvm_last_error().decode())
         alpha = d_alpha.cpu().numpy()
@@ -142,8 +153,6 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
     regularization, precision, shrinking, _cache, ncv, repeats, fast_estimation, random_seeds = args_svm[:8]
     if fast_estimation != 0:
         raise NotImplementedError("fast AUC estimation is dead code in the reference (its regressor is never loaded)")
-    if shrinking:
-        logging.info("the GPU solver does not shrink: same optimum as --shrinking 1 up to the tolerance")
     if random_seeds is not None and random_seeds < 0:
         random_seeds = None
     seqids = ["p%4d" % i for i in range(n_pseqs)] + ["n%4d" % i for i in range(n_nseqs)]
@@ -164,7 +173,7 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
     u_trains = [trains[u_of[w]] for w in uniq]
     u_tests = [tests[u_of[w]] for w in uniq]
     logging.info("cross-validation on the GPU: %d folds (%d distinct)", len(trains), len(uniq))
-    sol, handles = train_folds(K, u_trains, y, regularization, precision)
+    sol, handles = train_folds(K, u_trains, y, regularization, precision, bool(shrinking))
     scores = decision_values(K, handles, u_tests)
     capped = [f for f in range(len(u_trains)) if sol.iters[f] < 0]
     if capped:   # not converged within 10^7 iterations: the reference's solver has no cap, so use it for these folds
@@ -174,7 +183,7 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
             tr, te = u_trains[f], u_tests[f]
             ktr = device_block(K, tr, tr).cpu().numpy()
             kte = device_block(K, te, tr).cpu().numpy()
-            sv = SVC(kernel="precomputed", C=regularization, tol=precision, shrinking=False, cache_size=_cache)
+            sv = SVC(kernel="precomputed", C=regularization, tol=precision, shrinking=bool(shrinking), cache_size=_cache)
             scores[f] = sv.fit(ktr, y[tr]).decision_function(kte)
             sol.alpha[f] = np.abs(sv.dual_coef_[0])     # (only its sum is used below)
     u_auc = []

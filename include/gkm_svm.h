@@ -45,6 +45,17 @@ int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob
                        void *stream);
 
 /*
+ * The same with LIBSVM's shrinking heuristic (`shrinking` != 0; scikit-learn `SVC(shrinking=True)`, what the
+ * reference's `--shrinking 1` selects, scripts/gkmsvm.py:110-118) and for folds of up to 60 000 samples:
+ * Solver::Solve restated with do_shrinking / swap_index / reconstruct_gradient / G_bar, state in global
+ * memory, one workgroup per fold.  Bit-identical to scikit-learn with either setting (tests/test_svm_gpu.py);
+ * about 2x slower per iteration than gkmsvm_train_batch, which stays the path for gkmQC's default.
+ */
+int gkmsvm_train_batch_general(int device, const double *K, int64_t ld, int n, int nprob, const int *idx,
+                               const int64_t *off, const int *n0, double C, double eps, int shrinking, double *alpha,
+                               double *grad, double *rho, int *iters, void *stream);
+
+/*
  * Decision values of problem p for its test samples, in LIBSVM's summation order:
  *   dec[t] = sum_{k in training order, alpha_k > 0} alpha_k y_k K(test_t, train_k) - rho
  * (scikit-learn's decision_function returns the negative of this for a two-class problem).

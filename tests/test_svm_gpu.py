@@ -31,17 +31,17 @@ def _rbf_matrix(n, dim, seed, dup=0):
     return np.maximum(K, K.T)
 
 
-def _compare_with_sklearn(K, n_first, trains, tests, C, tol):
+def _compare_with_sklearn(K, n_first, trains, tests, C, tol, shrinking=False):
     import torch
     from sklearn.svm import SVC
     from gkmqc_amd import svmcv
     n = K.shape[0]
     y = np.concatenate((np.repeat(1, n_first), np.repeat(0, n - n_first)))
     Kd = torch.from_numpy(K).cuda()
-    sol, handles = svmcv.train_folds(Kd, trains, y, C, tol)
+    sol, handles = svmcv.train_folds(Kd, trains, y, C, tol, shrinking)
     scores = svmcv.decision_values(Kd, handles, tests)
     for f, (train, test) in enumerate(zip(trains, tests)):
-        sv = SVC(kernel="precomputed", C=C, tol=tol, shrinking=False, cache_size=512)
+        sv = SVC(kernel="precomputed", C=C, tol=tol, shrinking=shrinking, cache_size=512)
         sv.fit(K[train][:, train], y[train])
         coef, support = sol.dual_coef(f)
         # sklearn's support_ are positions in `train`
@@ -77,6 +77,61 @@ def test_solver_is_bit_identical_to_sklearn(built, n, dim, C, tol, dup):
     K = _rbf_matrix(n, dim, seed=n + dim, dup=dup)
     trains, tests = _folds(n, n // 2, 3, seed=1)
     _compare_with_sklearn(K, n // 2, trains, tests, C, tol)
+
+
+@pytest.mark.parametrize("n,dim,C,tol,dup", [
+    (200, 6, 1.0, 1e-3, 0),
+    (600, 10, 1.0, 1e-3, 0),
+    (600, 10, 0.05, 1e-3, 0),      # most alphas at the upper bound: G_bar in use
+    (400, 4, 100.0, 1e-4, 0),      # few bounded, many iterations: several rounds of shrinking, unshrink
+    (300, 5, 1.0, 1e-3, 40),       # duplicated samples: ties decided by the (permuted) position
+    (2600, 12, 1.0, 1e-3, 0),      # more than 1000 samples (shrinking every 1000 iterations), several per thread
+    (3000, 3, 10.0, 1e-5, 100),
+])
+def test_general_solver_with_shrinking_is_bit_identical_to_sklearn(built, n, dim, C, tol, dup):
+    """LIBSVM's shrinking (`--shrinking 1`): active-set permutation, G_bar, gradient reconstruction -- the support
+    set, dual coefficients, intercept and decision values of scikit-learn's SVC(shrinking=True), bit for bit."""
+    K = _rbf_matrix(n, dim, seed=n + dim, dup=dup)
+    trains, tests = _folds(n, n // 2, 3, seed=1)
+    _compare_with_sklearn(K, n // 2, trains, tests, C, tol, shrinking=True)
+    if tol < 1e-3:   # these run for thousands of iterations: shrinking changes LIBSVM's own result, so the match above means something
+        from sklearn.svm import SVC
+        y = np.concatenate((np.repeat(1, n // 2), np.repeat(0, n - n // 2)))
+        tr = trains[0]
+        a, b = (SVC(kernel="precomputed", C=C, tol=tol, shrinking=sh).fit(K[tr][:, tr], y[tr]) for sh in (True, False))
+        assert not (np.array_equal(a.support_, b.support_) and np.array_equal(a.dual_coef_, b.dual_coef_))
+
+
+def test_general_solver_without_shrinking(built, monkeypatch):
+    """The same kernel with shrinking off is the path of folds beyond k_smo's 16 384 samples; forced here on
+    small folds (FAST_FOLD_SAMPLES lowered), plus unbalanced and two-sample problems with shrinking on."""
+    from gkmqc_amd import svmcv
+    monkeypatch.setattr(svmcv, "FAST_FOLD_SAMPLES", 10)
+    K = _rbf_matrix(700, 8, seed=11, dup=10)
+    trains, tests = _folds(700, 350, 2, seed=2)
+    _compare_with_sklearn(K, 350, trains, tests, 1.0, 1e-3)
+    K = _rbf_matrix(90, 3, seed=5)
+    trains, tests = _folds(90, 12, 4, seed=3)
+    _compare_with_sklearn(K, 12, trains, tests, 1.0, 1e-3, shrinking=True)
+    _compare_with_sklearn(K, 12, [np.array([0, 50])], [np.array([1, 2, 60])], 1.0, 1e-3, shrinking=True)
+
+
+def test_cross_validation_with_shrinking_matches_sklearn(built, tmp_path):
+    """`--shrinking 1` end to end: the GPU cross-validation against the reference's scikit-learn harness on the
+    same (gkm) matrix."""
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    a = list(case["args_gkm"])
+    a[7], a[8] = POS, NEG
+    Kd, n_pos, n_neg = gkmsvm.computeGkmKernel(a, resident=True)
+    args_svm = list(case["args_svm"])
+    args_svm[2] = 1
+    got = gkmsvm.crossValidate(args_svm, Kd, n_pos, n_neg)
+    want = gkmsvm.crossValidate(args_svm, Kd.cpu().numpy(), n_pos, n_neg)
+    assert got == want
+    C, tol = args_svm[0], args_svm[1]
+    trains, tests = _folds(n_pos + n_neg, n_pos, args_svm[4], seed=args_svm[7])
+    _compare_with_sklearn(Kd.cpu().numpy(), n_pos, trains, tests, C, tol, shrinking=True)
 
 
 @pytest.mark.parametrize("shape", ["256x8", "512x8", "1024x4", "1024x8", "512x16", "1024x16"])
