@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--motif", type=float, default=0.5, help="fraction of positives carrying a planted motif")
     ap.add_argument("--sklearn", action="store_true", help="also time the reference's sklearn CV (host)")
     ap.add_argument("--procs", type=int, default=5)
+    ap.add_argument("--shrinking", type=int, default=0, help="LIBSVM's shrinking heuristic (the general GPU solver)")
+    ap.add_argument("--general", action="store_true", help="force the general GPU solver (k_smo_general) without shrinking")
     a = ap.parse_args()
     import torch
     from gkmqc_amd import gkmsvm, svmcv, synth
@@ -41,7 +43,9 @@ def main():
     synth.write_fasta(pos, ps, "p")
     synth.write_fasta(neg, ns, "n")
     args_gkm = [4, a.L, a.k, a.d, 50, 50, 1.0, pos, neg, 16, 0]
-    args_svm = [1.0, 0.001, 0, 512, a.ncv, a.repeats, 0, 7, a.procs]
+    args_svm = [1.0, 0.001, a.shrinking, 512, a.ncv, a.repeats, 0, 7, a.procs]
+    if a.general:
+        svmcv.FAST_FOLD_SAMPLES = 0
     t0 = time.time()
     K, n_pos, n_neg = gkmsvm.computeGkmKernel(args_gkm, resident=True)
     torch.cuda.synchronize()
