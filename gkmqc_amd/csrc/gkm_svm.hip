@@ -181,7 +181,7 @@ __global__ void k_diag(const double *__restrict__ K, int64_t ld, int n, double *
  * its payload in LDS, every thread then picks the block winner from the T/64 records and does
  * the (scalar) two-variable update redundantly, so no third exchange is needed.
  */
-template <int T, int SVM_R, bool TAB>
+template <int T, int SVM_R, int TABM>
 __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t ld, const double *__restrict__ diag,
                                            const SvmProb *probs, double C, double eps, int max_iter)
 {
@@ -195,11 +195,19 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     /* TAB: the samples' matrix indices and kernel diagonal live in (dynamic) LDS instead of
      * registers -- 48 VGPRs less at 16 samples per thread, which is what keeps alpha and G from
      * spilling to scratch (12 bytes per sample: up to 8192 samples in 96 KB of the CU's 160 KB) */
+    /* TABM = 2 (more than 8192 samples: 16 per thread at 4 waves per SIMD = 128 VGPRs): alpha in LDS (128 KB), the
+     * matrix indices in registers, the diagonal read from global memory where it is used (beside the gather of
+     * the matrix row, whose latency it shares), row i gathered a second time for the gradient update instead of
+     * kept.  With everything in registers this size spilt 712 bytes per thread to scratch: 5 folds x 16 000
+     * samples of config 3 took 0.86 s, against 0.083 s for 5 x 8 000. */
+    constexpr bool TAB = TABM == 1, QDG = TABM == 2, ALS = TABM == 2;
     extern __shared__ double dyn_lds[];
     double *const qd_s = dyn_lds;
+    double *const al_s = dyn_lds;
     int *const gidx_s = (int *)(dyn_lds + T * SVM_R);
-    int gidx[TAB ? 1 : SVM_R];
-    double qd[TAB ? 1 : SVM_R], al[SVM_R], G[SVM_R];
+    int gidx[TAB || TABM == 2 ? 1 : SVM_R];
+    double qd[TAB || QDG ? 1 : SVM_R], al[ALS ? 1 : SVM_R], G[SVM_R];
+    auto AL = [&](int r) { return ALS ? al_s[tid + r * T] : al[ALS ? 0 : r]; };
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
@@ -208,21 +216,25 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         if (TAB) {
             gidx_s[k] = g;
             qd_s[k] = dg;
-        } else {
-            gidx[r] = g;
-            qd[r] = dg;
+        } else if (!QDG) {
+            gidx[QDG ? 0 : r] = g;
+            qd[QDG ? 0 : r] = dg;
         }
-        al[r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1; stored as S = y G (see below) */
+        if (ALS) al_s[k] = 0.0;
+        else al[ALS ? 0 : r] = 0.0;  /* LIBSVM: alpha = 0, G = p = -1; stored as S = y G (see below) */
         G[r] = k < n0 ? -1.0 : 1.0;
     }
-    if (TAB) __syncthreads();
+    if (TAB || ALS) __syncthreads();
     /* The gradient is kept as S_k = y_k G_k and kernel values without LIBSVM's y_i y_k factor: every
      * use of G and Q in the solver carries the matching sign (-y G in the first selection, y G in
      * the second and in rho, Q_ik dalpha_i = y_k (float)K_ik (y_i dalpha_i) in the update), negation
      * and rounding commute, so the arithmetic is LIBSVM's bit for bit with no per-sample sign
      * selects.  G[] below holds S. */
-    auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : gidx[TAB ? 0 : r]; };
-    auto QD = [&](int r) { return TAB ? qd_s[tid + r * T] : qd[TAB ? 0 : r]; };
+    /* (TABM = 2: the index list itself, 64 KB in L2, read again wherever an index is needed -- kept in registers the
+     * 16 indices turn into 16 64-bit row offsets that live through the whole iteration) */
+    int tv = tid; /* = tid, re-made opaque every iteration so that hipcc does not hoist 16 64-bit addresses out of the loop (they spilt) */
+    auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : QDG ? p.idx[min(tv + r * T, l - 1)] : gidx[TAB || QDG ? 0 : r]; };
+    auto QD = [&](int r) { return QDG ? diag[GI(r)] : TAB ? qd_s[tid + r * T] : qd[TAB || QDG ? 0 : r]; };
 
 #ifdef SVM_PROF
     long long tp[6] = {0, 0, 0, 0, 0, 0}, t0 = clock64(), t1;
@@ -233,6 +245,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     int iter = 0;
     for (;; iter++) {
         if (iter >= max_iter) { iter = -iter; break; }
+        if (QDG) asm volatile("" : "+v"(tv));
         PROF(5)
         /* ---- first index: argmax over I_up of -y G ---- */
         /* (branch-free: k grows with r, so inside a thread "replace on >=" is LIBSVM's tie rule) */
@@ -242,11 +255,13 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         for (int r = 0; r < SVM_R; r++) {
             const int k = tid + r * T;
             const bool pos = k < n0; /* y = +1 */
-            const bool below_C = al[r] < C, above_0 = al[r] > 0.0; /* (bitwise: no branches) */
+            const double a_r = AL(r);
+            const bool below_C = a_r < C, above_0 = a_r > 0.0; /* (bitwise: no branches) */
             const bool in_up = (k < l) & ((pos & below_C) | (!pos & above_0));
             const bool take = in_up & (G[r] <= ns);
             ns = take ? G[r] : ns;
             bk = take ? k : bk;
+            if (ALS && (r & 3) == 3) __builtin_amdgcn_sched_barrier(0); /* (keeps hipcc from fetching all 16 alphas at once) */
         }
         double bv = -ns;
         PROF(0)
@@ -258,7 +273,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             const bool owner = (bk & 63) == lane;
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
-                if (r == rr && owner) candA[wave] = {bv, al[r], (bk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r], 0.0, bk, TAB ? 0 : gidx[TAB ? 0 : r]};
+                if (r == rr && owner) candA[wave] = {bv, AL(r), (bk < n0 ? G[r] : -G[r]), TAB || QDG ? 0.0 : qd[TAB || QDG ? 0 : r], 0.0, bk, TAB ? 0 : QDG ? GI(r) : gidx[TAB || QDG ? 0 : r]};
         }
         __syncthreads();
         /* the NW wave winners: one per lane of a row, DPP selection, then one broadcast read */
@@ -273,33 +288,49 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         const double Gmax = ci.v;
         const double yi = i < n0 ? 1.0 : -1.0;
         const double *Ki = K + (int64_t)(TAB ? gidx_s[i] : ci.g) * ld;
-        const double QDi = TAB ? qd_s[i] : ci.qd;
+        const double QDi = QDG ? diag[ci.g] : TAB ? qd_s[i] : ci.qd;
 
         /* ---- second index: argmin over I_low of -(grad_diff^2)/quad, and Gmax2 ---- */
-        float kfi[SVM_R]; /* (float)K_ik: LIBSVM's Qfloat without its sign y_i y_k */
-        double kik[SVM_R];
+        /* (float)K_ik: LIBSVM's Qfloat without its sign y_i y_k; TABM = 2 does not keep the 16 of them but reads
+         * row i again for the gradient update (a third gather per iteration is cheaper than the spills) */
+        constexpr bool KEEP = !QDG;
+        float kfi[KEEP ? SVM_R : 1], mkf = 0.0f;
         double mv = INFINITY, g2max = -INFINITY;
         int mk = -1;
+        /* (8 samples at a time: at 16 per thread the 16 doubles of the row and, TABM = 2, of the diagonal in flight
+         * together were what spilt) */
+        constexpr int BATCH = QDG ? 8 : SVM_R; /* (one batch = the loops as they were for the other shapes) */
 #pragma unroll
-        for (int r = 0; r < SVM_R; r++) kik[r] = Ki[GI(r)]; /* lanes past l read column 0 */
+        for (int r0 = 0; r0 < SVM_R; r0 += BATCH) {
+        double kik[BATCH], qdr[QDG ? BATCH : 1];
+#pragma unroll
+        for (int r = r0; r < r0 + BATCH; r++) { /* lanes past l read column 0 */
+            kik[r - r0] = Ki[GI(r)];
+            if (QDG) qdr[QDG ? r - r0 : 0] = QD(r);
+        }
         /* 2 y_i Q_ik = +-2 (float)K_ik with the sign of y_k, so LIBSVM's two quad_coef expressions are
          * both (QD_i + QD_k) - 2 (float)K_ik, bit for bit; the loop is branch-free (selects), one IEEE
          * division per sample */
 #pragma unroll
-        for (int r = 0; r < SVM_R; r++) {
+        for (int r = r0; r < r0 + BATCH; r++) {
             const int k = tid + r * T;
             const bool pos = k < n0;
-            kfi[r] = (float)kik[r];
-            const bool below_C = al[r] < C, above_0 = al[r] > 0.0;
+            const float kf = (float)kik[r - r0];
+            if (KEEP) kfi[KEEP ? r : 0] = kf;
+            const double a_r = AL(r);
+            const bool below_C = a_r < C, above_0 = a_r > 0.0;
             const bool in_low = (k < l) & ((pos & above_0) | (!pos & below_C));
             const double gs = G[r]; /* y_k G_k */
             g2max = (in_low & (gs > g2max)) ? gs : g2max;
             const double grad_diff = Gmax + gs;
-            const double quad = (QDi + QD(r)) - 2.0 * (double)kfi[r];
+            const double quad = (QDi + (QDG ? qdr[QDG ? r - r0 : 0] : QD(r))) - 2.0 * (double)kf;
             const double od = -(grad_diff * grad_diff) / (quad > 0.0 ? quad : SVM_TAU);
             const bool take = in_low & (grad_diff > 0.0) & (od <= mv);
             mv = take ? od : mv;
             mk = take ? k : mk;
+            if (!KEEP) mkf = take ? kf : mkf;
+        }
+        if (ALS) __builtin_amdgcn_sched_barrier(0);
         }
         PROF(2)
         g2max = wave_max(g2max);
@@ -313,8 +344,8 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
             for (int r = 0; r < SVM_R; r++)
                 if (r == rr && owner)
-                    candB[wave] = {mv, al[r], (mk < n0 ? G[r] : -G[r]), TAB ? 0.0 : qd[TAB ? 0 : r],
-                                   (double)((yi > 0.0) == (mk < n0) ? kfi[r] : -kfi[r]), mk, TAB ? 0 : gidx[TAB ? 0 : r]};
+                    candB[wave] = {mv, AL(r), (mk < n0 ? G[r] : -G[r]), TAB || QDG ? 0.0 : qd[TAB || QDG ? 0 : r],
+                                   (double)((yi > 0.0) == (mk < n0) ? (KEEP ? kfi[KEEP ? r : 0] : mkf) : -(KEEP ? kfi[KEEP ? r : 0] : mkf)), mk, TAB ? 0 : QDG ? GI(r) : gidx[TAB || QDG ? 0 : r]};
         }
         __syncthreads();
         wk = candB[lane & (NW - 1)].k;
@@ -329,7 +360,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 
         /* ---- the two-variable sub-problem, LIBSVM's clipping order (every thread, same result) ---- */
         const double yj = j < n0 ? 1.0 : -1.0;
-        const double Qij = cj.q, QDj = TAB ? qd_s[j] : cj.qd;
+        const double Qij = cj.q, QDj = QDG ? diag[cj.g] : TAB ? qd_s[j] : cj.qd;
         double ai = ci.alpha, aj = cj.alpha;
         const double old_i = ai, old_j = aj;
         {
@@ -366,19 +397,32 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 
         /* ---- gradient; the owners store the new alpha ---- */
         const double *Kj = K + (int64_t)(TAB ? gidx_s[j] : cj.g) * ld;
-        double kj[SVM_R];
-#pragma unroll
-        for (int r = 0; r < SVM_R; r++) kj[r] = Kj[GI(r)];
         const double ci_ = yi * dai, cj_ = yj * daj;
         const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
         const int ri = iu / T, rj = ju / T;
         const bool mine_i = (iu & (T - 1)) == tid, mine_j = (ju & (T - 1)) == tid;
 #pragma unroll
-        for (int r = 0; r < SVM_R; r++) { /* (lanes past l update a gradient nobody reads) */
-            G[r] += (double)kfi[r] * ci_ + (double)(float)kj[r] * cj_;
+        for (int r0 = 0; r0 < SVM_R; r0 += BATCH) {
+        double kj[BATCH], ki2[KEEP ? 1 : BATCH];
+#pragma unroll
+        for (int r = r0; r < r0 + BATCH; r++) {
+            kj[r - r0] = Kj[GI(r)];
+            if (!KEEP) ki2[KEEP ? 0 : r - r0] = Ki[GI(r)];
+        }
+#pragma unroll
+        for (int r = r0; r < r0 + BATCH; r++) { /* (lanes past l update a gradient nobody reads) */
+            const float kf = KEEP ? kfi[KEEP ? r : 0] : (float)ki2[KEEP ? 0 : r - r0];
+            G[r] += (double)kf * ci_ + (double)(float)kj[r - r0] * cj_;
             /* (i and j are wave-uniform: scalar tests pick the one register each of them lives in) */
-            if (r == ri) al[r] = mine_i ? ai : al[r];
-            if (r == rj) al[r] = mine_j ? aj : al[r];
+            if (ALS) {
+                if (r == ri && mine_i) al_s[tid + r * T] = ai;
+                if (r == rj && mine_j) al_s[tid + r * T] = aj;
+            } else {
+                if (r == ri) al[ALS ? 0 : r] = mine_i ? ai : al[ALS ? 0 : r];
+                if (r == rj) al[ALS ? 0 : r] = mine_j ? aj : al[ALS ? 0 : r];
+            }
+        }
+        if (ALS) __builtin_amdgcn_sched_barrier(0);
         }
         PROF(4)
     }
@@ -391,7 +435,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
-        if (k < l) { p.alpha[k] = al[r]; p.grad[k] = k < n0 ? G[r] : -G[r]; }
+        if (k < l) { p.alpha[k] = AL(r); p.grad[k] = k < n0 ? G[r] : -G[r]; }
     }
 
     /* rho (LIBSVM calculate_rho).  The mean over the free vectors is summed in index order by one
@@ -406,9 +450,9 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         double yG = G[r]; /* S = y G */
         bool is_free = false;
         if (k < l) {
-            if (al[r] >= C) {
+            if (AL(r) >= C) {
                 if (y < 0) ub = fmin(ub, yG); else lb = fmax(lb, yG);
-            } else if (al[r] <= 0) {
+            } else if (AL(r) <= 0) {
                 if (y > 0) ub = fmin(ub, yG); else lb = fmax(lb, yG);
             } else {
                 is_free = true;
@@ -917,21 +961,21 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     }
 #define SMO_LAUNCH(TT, RR, TB)                                                                                  \
     if (T == TT && R == RR) {                                                                                   \
-        const size_t dyn = TB ? (size_t)TT * RR * 12 : 0;                                                       \
+        const size_t dyn = TB == 1 ? (size_t)TT * RR * 12 : TB == 2 ? (size_t)TT * RR * 8 : 0;                  \
         if (dyn > 0)                                                                                            \
             SVMCHK(hipFuncSetAttribute((const void *)k_smo<TT, RR, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                        (int)dyn));                                                              \
         hipLaunchKernelGGL((k_smo<TT, RR, TB>), dim3((unsigned)nprob), dim3(TT), dyn, stream, K, ld, diag, dprobs, C, \
                            eps, max_iter);                                                                      \
     } else
-    SMO_LAUNCH(256, 4, true)
-    SMO_LAUNCH(512, 4, true)
-    SMO_LAUNCH(256, 8, true)
-    SMO_LAUNCH(512, 8, true)
-    SMO_LAUNCH(1024, 4, true)
-    SMO_LAUNCH(1024, 8, true)
-    SMO_LAUNCH(512, 16, true)
-    SMO_LAUNCH(1024, 16, false)
+    SMO_LAUNCH(256, 4, 1)
+    SMO_LAUNCH(512, 4, 1)
+    SMO_LAUNCH(256, 8, 1)
+    SMO_LAUNCH(512, 8, 1)
+    SMO_LAUNCH(1024, 4, 1)
+    SMO_LAUNCH(1024, 8, 1)
+    SMO_LAUNCH(512, 16, 1)
+    SMO_LAUNCH(1024, 16, 2)
     {
         g_svm_err = "GKM_SVM_SHAPE: unsupported shape";
         (void)hipFree(diag);
