@@ -1133,14 +1133,16 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t);
         bool bperm = false;
         if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
-            hipFuncAttributes fa;
+            hipFuncAttributes fa, fb;
             const char *force = getenv("GKM_FORCE_BPERM");
+            bs_kernel_t bsp = pick_bitslice<10, 3>(L, d);
             auto granules = [](size_t bytes) { return (bytes + 1279) / 1280; };
             if (force ? atoi(force) != 0
                       : (hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess &&
-                         granules(fa.sharedSizeBytes + dyn_lds) > granules(fa.sharedSizeBytes - 508 + dyn_lds)))
+                         hipFuncGetAttributes(&fb, (const void *)bsp) == hipSuccess &&
+                         granules(fa.sharedSizeBytes + dyn_lds) > granules(fb.sharedSizeBytes + dyn_lds)))
                 bperm = true;
-            if (bperm) bs = pick_bitslice<10, 3>(L, d);
+            if (bperm) bs = bsp;
         }
         if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t nl = (size_t)ntiles * 64;
