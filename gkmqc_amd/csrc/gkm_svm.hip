@@ -300,6 +300,27 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
         /* (8 samples at a time: at 16 per thread the 16 doubles of the row and, TABM = 2, of the diagonal in flight
          * together were what spilt) */
         constexpr int BATCH = QDG ? 8 : SVM_R; /* (one batch = the loops as they were for the other shapes) */
+        if constexpr (!QDG) { /* the loops as they have always been for these shapes */
+            double kik[SVM_R];
+#pragma unroll
+            for (int r = 0; r < SVM_R; r++) kik[r] = Ki[GI(r)]; /* lanes past l read column 0 */
+#pragma unroll
+            for (int r = 0; r < SVM_R; r++) {
+                const int k = tid + r * T;
+                const bool pos = k < n0;
+                kfi[KEEP ? r : 0] = (float)kik[r];
+                const bool below_C = al[ALS ? 0 : r] < C, above_0 = al[ALS ? 0 : r] > 0.0;
+                const bool in_low = (k < l) & ((pos & above_0) | (!pos & below_C));
+                const double gs = G[r]; /* y_k G_k */
+                g2max = (in_low & (gs > g2max)) ? gs : g2max;
+                const double grad_diff = Gmax + gs;
+                const double quad = (QDi + QD(r)) - 2.0 * (double)kfi[KEEP ? r : 0];
+                const double od = -(grad_diff * grad_diff) / (quad > 0.0 ? quad : SVM_TAU);
+                const bool take = in_low & (grad_diff > 0.0) & (od <= mv);
+                mv = take ? od : mv;
+                mk = take ? k : mk;
+            }
+        } else {
 #pragma unroll
         for (int r0 = 0; r0 < SVM_R; r0 += BATCH) {
         double kik[BATCH], qdr[QDG ? BATCH : 1];
@@ -331,6 +352,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
             if (!KEEP) mkf = take ? kf : mkf;
         }
         if (ALS) __builtin_amdgcn_sched_barrier(0);
+        }
         }
         PROF(2)
         g2max = wave_max(g2max);
@@ -397,22 +419,29 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 
         /* ---- gradient; the owners store the new alpha ---- */
         const double *Kj = K + (int64_t)(TAB ? gidx_s[j] : cj.g) * ld;
+        double kja[KEEP ? SVM_R : 1]; /* (the gather of row j goes out before anything else of this phase) */
+        if (KEEP) {
+#pragma unroll
+            for (int r = 0; r < SVM_R; r++) kja[KEEP ? r : 0] = Kj[GI(r)];
+        }
         const double ci_ = yi * dai, cj_ = yj * daj;
         const int iu = __builtin_amdgcn_readfirstlane(i), ju = __builtin_amdgcn_readfirstlane(j);
         const int ri = iu / T, rj = ju / T;
         const bool mine_i = (iu & (T - 1)) == tid, mine_j = (ju & (T - 1)) == tid;
 #pragma unroll
         for (int r0 = 0; r0 < SVM_R; r0 += BATCH) {
-        double kj[BATCH], ki2[KEEP ? 1 : BATCH];
+        double kj[KEEP ? 1 : BATCH], ki2[KEEP ? 1 : BATCH];
+        if (!KEEP) {
 #pragma unroll
-        for (int r = r0; r < r0 + BATCH; r++) {
-            kj[r - r0] = Kj[GI(r)];
-            if (!KEEP) ki2[KEEP ? 0 : r - r0] = Ki[GI(r)];
+            for (int r = r0; r < r0 + BATCH; r++) {
+                kj[KEEP ? 0 : r - r0] = Kj[GI(r)];
+                ki2[KEEP ? 0 : r - r0] = Ki[GI(r)];
+            }
         }
 #pragma unroll
         for (int r = r0; r < r0 + BATCH; r++) { /* (lanes past l update a gradient nobody reads) */
             const float kf = KEEP ? kfi[KEEP ? r : 0] : (float)ki2[KEEP ? 0 : r - r0];
-            G[r] += (double)kf * ci_ + (double)(float)kj[r - r0] * cj_;
+            G[r] += (double)kf * ci_ + (double)(float)(KEEP ? kja[KEEP ? r : 0] : kj[KEEP ? 0 : r - r0]) * cj_;
             /* (i and j are wave-uniform: scalar tests pick the one register each of them lives in) */
             if (ALS) {
                 if (r == ri && mine_i) al_s[tid + r * T] = ai;
