@@ -118,6 +118,41 @@ def test_general_solver_without_shrinking(built, monkeypatch):
     _compare_with_sklearn(K, 12, [np.array([0, 50])], [np.array([1, 2, 60])], 1.0, 1e-3, shrinking=True)
 
 
+def test_large_folds_both_solvers_agree(built, monkeypatch):
+    """16 000-sample folds (config 3's size): k_smo's 16-samples-per-thread shape (alpha in LDS, indices and
+    diagonal re-read) against the general solver, which keeps its state in global memory -- same alpha, gradient,
+    rho and iteration count bit for bit; and a fold beyond k_smo's 16 384 samples converges on the general solver
+    (KKT violation below the tolerance).  scikit-learn itself would take minutes here; both solvers are pinned
+    to it at smaller sizes above."""
+    import torch
+    from gkmqc_amd import svmcv
+    n, dim = 17600, 6
+    g = torch.Generator(device="cpu").manual_seed(5)
+    X = torch.randn(n, dim, generator=g, dtype=torch.float64)
+    X[: n // 2] += 0.5
+    X = X.cuda()
+    sq = (X * X).sum(1)
+    K = torch.exp(-(sq[:, None] + sq[None, :] - 2.0 * X @ X.T).clamp_min(0) / (2.0 * dim))
+    K = torch.maximum(K, K.T).contiguous()
+    y = np.concatenate((np.repeat(1, n // 2), np.repeat(0, n - n // 2)))
+    idx = np.random.default_rng(3).permutation(n)
+    train = np.sort(idx[:16000])
+    a, _ = svmcv.train_folds(K, [train], y, 1.0, 1e-3)
+    monkeypatch.setattr(svmcv, "FAST_FOLD_SAMPLES", 0)
+    b, _ = svmcv.train_folds(K, [train], y, 1.0, 1e-3)
+    assert a.iters[0] > 0 and a.iters[0] == b.iters[0]
+    assert np.array_equal(a.alpha[0], b.alpha[0]) and np.array_equal(a.grad[0], b.grad[0]) and a.rho[0] == b.rho[0]
+    monkeypatch.setattr(svmcv, "FAST_FOLD_SAMPLES", 16384)
+    big = np.sort(idx[:17500])
+    c, _ = svmcv.train_folds(K, [big], y, 1.0, 1e-3)
+    assert c.iters[0] > 0
+    al, gr = c.alpha[0], c.grad[0]
+    ys = np.where(np.arange(len(al)) < c.n0[0], 1.0, -1.0)
+    up = ((ys > 0) & (al < 1.0)) | ((ys < 0) & (al > 0))
+    low = ((ys > 0) & (al > 0)) | ((ys < 0) & (al < 1.0))
+    assert (-(ys * gr))[up].max() + (ys * gr)[low].max() < 1e-3      # LIBSVM's stopping criterion
+
+
 def test_cross_validation_with_shrinking_matches_sklearn(built, tmp_path):
     """`--shrinking 1` end to end: the GPU cross-validation against the reference's scikit-learn harness on the
     same (gkm) matrix."""
