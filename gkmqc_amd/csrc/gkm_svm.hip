@@ -986,6 +986,8 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
         else if (maxl <= 512 * 4) { T = 512; R = 4; }
         else if (maxl <= 512 * 8) { T = 512; R = 8; }
         else if (maxl <= 1024 * 8) { T = 1024; R = 8; } /* (512x16: 113 ms against 99 ms at 8000 samples) */
+        else if (maxl <= 1024 * 10) { T = 1024; R = 10; } /* e.g. 10-fold cross-validation of 10 000 sequences */
+        else if (maxl <= 1024 * 12) { T = 1024; R = 12; }
         else { T = 1024; R = 16; }
     }
 #define SMO_LAUNCH(TT, RR, TB)                                                                                  \
@@ -1003,6 +1005,8 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     SMO_LAUNCH(512, 8, 1)
     SMO_LAUNCH(1024, 4, 1)
     SMO_LAUNCH(1024, 8, 1)
+    SMO_LAUNCH(1024, 10, 1)
+    SMO_LAUNCH(1024, 12, 1)
     SMO_LAUNCH(512, 16, 1)
     SMO_LAUNCH(1024, 16, 2)
     {

@@ -171,7 +171,7 @@ def test_cross_validation_with_shrinking_matches_sklearn(built, tmp_path):
     _compare_with_sklearn(Kd.cpu().numpy(), n_pos, trains, tests, C, tol, shrinking=True)
 
 
-@pytest.mark.parametrize("shape", ["256x8", "512x8", "1024x4", "1024x8", "512x16", "1024x16"])
+@pytest.mark.parametrize("shape", ["256x8", "512x8", "1024x4", "1024x8", "1024x10", "1024x12", "512x16", "1024x16"])
 def test_every_launch_shape(built, monkeypatch, shape):
     """The launcher picks threads x samples-per-thread from the fold size; force each instantiation
     (incl. the register-table variant used above 8192 samples) on the same problem."""
