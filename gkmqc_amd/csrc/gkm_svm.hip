@@ -2,7 +2,7 @@
  * gkm_svm.hip -- C-SVC on a precomputed kernel resident in HBM (include/gkm_svm.h, SURVEY.md
  * §8(f4)).  One workgroup per problem (cross-validation fold); all folds of a CV run
  * concurrently on different CUs.  The iteration is LIBSVM's SMO with second-order working-set
- * selection and no shrinking (Fan, Chen, Lin 2005), restated so that every floating-point
+ * selection and no shrinking (Fan, Chen, Lin 2005; with shrinking: k_smo_general below), restated so that every floating-point
  * operation and every tie break matches the sequential solver: same alpha, same rho.
  *
  * Per iteration (l = training samples, each thread owns up to R of them, strided):

@@ -5,8 +5,8 @@
  * StratifiedKFold x repeats -> sklearn.svm.SVC(kernel="precomputed") -> decision_function).
  *
  * What it replaces: the LIBSVM solver inside scikit-learn (sklearn/svm/src/libsvm/svm.cpp,
- * `Solver::Solve` with second-order working-set selection, no shrinking -- gkmQC's default
- * `--shrinking 0`).  That code is a third-party dependency of the reference, not part of
+ * `Solver::Solve` with second-order working-set selection; gkmsvm_train_batch without the shrinking
+ * heuristic -- gkmQC's default `--shrinking 0` --, gkmsvm_train_batch_general with or without it).  That code is a third-party dependency of the reference, not part of
  * /root/reference; the algorithm restated here is Fan, Chen, Lin (2005) "Working set selection
  * using second order information" as implemented by LIBSVM 3.x: same iteration sequence, same
  * tie breaking, kernel values rounded to float as LIBSVM's Qfloat, all other arithmetic fp64.
