@@ -474,7 +474,9 @@ static_assert(BS_TRIP == 64, "a trip resolves one record per lane");
 constexpr int BS_CAP = BS_TRIP + 64;
 constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 #ifndef GKM_BS_DU
-#define GKM_BS_DU 2 /* A/B on config 2 (final kernel, same box): 1 -> 84.9 ms, 2 -> 84.3, 3 -> 85.2, 4..6 -> 85.3 */
+#define GKM_BS_DU 4 /* shifts per refill of the column words.  Round 2's final kernel, same-run A/B, config 2 / gkmQC's
+                       defaults / config 5: 1 -> 78.2 / 437.2 / 177.9 ms, 2 -> 77.0-77.5 / 436.8-437.6 / 176.7, 3 -> 76.7 / 437.0 /
+                       176.2, 4 -> 76.4-76.8 / 436.7-438.6 / 175.6-175.8, 5, 6, 8 -> 79.1-79.4 / 452-454 / 176.5 */
 #endif
 #ifndef GKM_BS_WAVES
 #define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
