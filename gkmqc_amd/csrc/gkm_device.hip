@@ -502,7 +502,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
      *      3: as 0, but a trip fetches the source lane's piece entry from that lane's registers (ds_bpermute_b32)
      *         instead of a 512-byte table in LDS -- taken when those 512 bytes cost an LDS allocation granule,
-     *         i.e. waves per CU (rows and columns of 600 bp: 25 -> 32 one-wave workgroups per CU, 449 -> 436 ms
+     *         i.e. waves per CU (rows and columns of 600 bp: 24 -> 32 one-wave workgroups per CU by LDS, 449 -> 436 ms
      *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
     constexpr bool PACKED = PK == 1 || PK == 2;
     constexpr bool BPERM = PK == 3;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     /* BPERM: the lane keeps its own (row slot * 4, biased centre offset) in two registers and a trip fetches
      * the source lane's pair over the permute network (ds_bpermute_b32: no LDS storage, no bank conflicts).
      * The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation granules of 1 280
-     * (tools/lds_occupancy.hip): 32 instead of 25 one-wave workgroups fit a CU at 600 bp. */
+     * (tools/lds_occupancy.hip): 32 instead of 24 one-wave workgroups fit a CU at 600 bp. */
     uint32_t my_slot4 = 0u, my_c0b = 0u;
     if (BPERM) {
         my_slot4 = A.lane_piece[(size_t)(tile * 64 + lane) * 2];
