@@ -115,3 +115,23 @@ def test_config4_stand_in_at_full_size(built, tmp_path, gpus):
     assert helpers.max_rel_err(kmat[case["sample_i"], case["sample_j"]], np.array(case["sample_v"])) < 1e-12
     assert hashlib.sha256(np.ascontiguousarray(kmat).tobytes()).hexdigest() == case["kmat_sha256"], \
         "matrix differs from the reference's in the last bits"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,rng", [(4400, None), (2000, (150, 600))])
+def test_boundary_blocks_and_pieces_against_one_launch(built, tmp_path, monkeypatch, n, rng):
+    """The drop-in call cuts the matrix into geometrically shrinking row blocks (one Gram launch each) that travel
+    to the caller's rows in staging-sized pieces; at 4 400 rows the first block needs two pieces.  Bit for bit the
+    matrix the device layer computes in one launch, also with the equal-area blocks kept for A/B runs."""
+    from gkmqc_amd import gkmsvm, synth
+    pos, neg = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+    synth.write_problem(pos, neg, n // 2, n - n // 2, 300, rng)
+    L, k, d = (11, 7, 3) if rng is None else (12, 8, 4)
+    args = [4, L, k, d, 50, 50.0, 1.0, pos, neg, 8, 0]
+    want, n_pos, n_neg = gkmsvm.computeGkmKernel(args, backend="device")
+    assert (n_pos, n_neg) == (n // 2, n - n // 2)
+    got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("GKM_EQUAL_BLOCKS", "1")
+    got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+    assert np.array_equal(got, want)
