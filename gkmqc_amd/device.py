@@ -355,13 +355,14 @@ def cross_kernel(seqs, rows, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devi
 _CTX_CACHE = {}
 
 
-def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0):
+def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, slot=0):
     """One long-lived GramContext per (device, parameters).  Destroying a context frees device memory,
     which waits for EVERYTHING on the device (hipFree): a caller that evaluates subset after subset
     with the cross-validation of the previous one still running on another stream (gkmsvm.init_many)
     keeps its context instead, re-uploads the next subset's sequences into the same buffers and so
-    never blocks on the other stream."""
-    key = (device, kernel_type, L, k, d, int(M), float(H), float(gamma))
+    never blocks on the other stream.  `slot` tells apart callers that work on the same device at the same time
+    (gkmsvm.init_many with one worker per entry of `gpus`)."""
+    key = (device, slot, kernel_type, L, k, d, int(M), float(H), float(gamma))
     ctx = _CTX_CACHE.get(key)
     if ctx is None or not ctx.handle:
         ctx = _CTX_CACHE[key] = GramContext(kernel_type, L, k, d, M, H, gamma, device)
@@ -375,14 +376,14 @@ def release_cached_contexts():
 
 
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,
-                kernel=KERNEL_AUTO, symmetric=False, keep_context=False):
+                kernel=KERNEL_AUTO, symmetric=False, keep_context=False, context_slot=0):
     """Whole Gram matrix of `seqs` on one GPU (device memory through torch).
 
     Returns dict(K=torch fp64 [n,n] (lower triangle + unit diagonal; upper too if symmetric),
     P=int32 [n,n,d+1] or None, sqnorm=[n], kernel=name, ms=device ms of the gram kernel).
     keep_context: use (and keep) the cached context of these parameters, see cached_context()."""
     import torch
-    ctx = (cached_context(kernel_type, L, k, d, M, H, gamma, device) if keep_context
+    ctx = (cached_context(kernel_type, L, k, d, M, H, gamma, device, context_slot) if keep_context
            else GramContext(kernel_type, L, k, d, M, H, gamma, device))
     try:
         ctx.set_kernel(kernel)

@@ -35,7 +35,7 @@ from . import device
 _KMAT = None  # shared with forked CV workers, like the reference's module global
 
 
-def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, keep_context=False):
+def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, keep_context=False, context_slot=0):
     """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity].
 
     gpus > 1 (or a list of device ordinals): the matrix is computed on that many GPUs of the node by
@@ -69,7 +69,7 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, 
         del res
     else:
         K = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=devices[0],
-                               keep_context=keep_context)["K"]
+                               keep_context=keep_context, context_slot=context_slot)["K"]
     K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97 (lower triangle + unit diagonal, zeros above)
     if resident:
         return K, n_pos, len(seqs) - n_pos
@@ -145,18 +145,12 @@ def init(pos_fa, neg_fa, args):
     return auc_score, auc_std
 
 
-def init_many(pairs, args, gpu=0):
-    """`init` for several (pos_fa, neg_fa) subsets in a row -- what `bin/gkmqc.py evaluate` does with its peak
-    subsets -- with the two GPU stages overlapped: the cross-validation of subset s (a handful of workgroups, one
-    CU each) runs on a second HIP stream while the Gram kernel of subset s+1 has the rest of the GPU.  Same
-    numbers and the same lines in <name>.gkmqc.eval.out, in order, as one `init` per subset; measured per subset
-    at 5 000 + 5 000 sequences: 150 -> 117 ms (300 bp), 384 -> 343 ms (600 bp)."""
+def _init_many_on(pairs, args, gpu, slot):
+    """The subsets of `pairs`, one after the other on one GPU, the cross-validation of subset s on a second HIP
+    stream while the Gram kernel of subset s+1 has the rest of the GPU.  Returns [(auc, std, n_pos)]."""
     import queue
     import threading
     import torch
-    from . import svmcv
-    if getattr(args, "svm_solver", "gpu") != "gpu" or len(pairs) < 2:
-        return [init(p, n, args) for p, n in pairs]
     dev = torch.device("cuda", gpu)
     gram_stream = torch.cuda.Stream(dev)
     cv_stream = torch.cuda.Stream(dev, priority=-1)
@@ -196,7 +190,8 @@ def init_many(pairs, args, gpu=0):
                         args.verbosity]
             with torch.cuda.stream(gram_stream):
                 # (one context for all subsets: closing one would wait for the other stream's solver, hipFree)
-                K, n_pos, n_neg = computeGkmKernel(args_gkm, gpu=gpu, resident=True, keep_context=True)
+                K, n_pos, n_neg = computeGkmKernel(args_gkm, gpu=gpu, resident=True, keep_context=True,
+                                                   context_slot=slot)
                 gram_stream.synchronize()
             handoff.put((s, K, n_pos, n_neg))
             del K
@@ -205,6 +200,46 @@ def init_many(pairs, args, gpu=0):
         th.join()
     if errors:
         raise errors[0]
+    return results
+
+
+def init_many(pairs, args, gpu=0, gpus=None):
+    """`init` for several (pos_fa, neg_fa) subsets in a row -- what `bin/gkmqc.py evaluate` does with its peak
+    subsets -- with the two GPU stages overlapped: the cross-validation of subset s (a handful of workgroups, one
+    CU each) runs on a second HIP stream while the Gram kernel of subset s+1 has the rest of the GPU.  Same
+    numbers and the same lines in <name>.gkmqc.eval.out, in order, as one `init` per subset; measured per subset
+    at 5 000 + 5 000 sequences: 150 -> 117 ms (300 bp), 384 -> 343 ms (600 bp).
+
+    gpus (a list of device ordinals): the subsets are independent, so they are dealt round-robin to one worker per
+    entry -- each with its own context, streams and share of the subsets, no exchange between GPUs (the 20 subsets
+    of an `evaluate` run on 8 GPUs: 3 rounds instead of 20).  The results and the eval lines keep the order of
+    `pairs`."""
+    import threading
+    if getattr(args, "svm_solver", "gpu") != "gpu" or len(pairs) < 2:
+        return [init(p, n, args) for p, n in pairs]
+    devices = list(gpus) if gpus else [gpu]
+    devices = devices[:len(pairs)]
+    if len(devices) == 1:
+        results = _init_many_on(pairs, args, devices[0], 0)
+    else:
+        results = [None] * len(pairs)
+        errors = []
+
+        def work(w):
+            mine = list(range(w, len(pairs), len(devices)))
+            try:
+                for s, r in zip(mine, _init_many_on([pairs[s] for s in mine], args, devices[w], w)):
+                    results[s] = r
+            except BaseException as e:      # re-raised below
+                errors.append(e)
+
+        workers = [threading.Thread(target=work, args=(w,)) for w in range(len(devices))]
+        for t in workers:
+            t.start()
+        for t in workers:
+            t.join()
+        if errors:
+            raise errors[0]
     with open(args.name + ".gkmqc.eval.out", "a") as fa:
         for (pos_fa, neg_fa), (auc, std, n_pos) in zip(pairs, results):
             fa.write("\t".join(map(str, [pos_fa, neg_fa, n_pos, auc, std])) + "\n")

@@ -86,6 +86,12 @@ def test_init_many_overlaps_and_matches_init(built, tmp_path):
     assert got == want
     assert abs(got[0][0] - case["auc_mean"]) < 1e-12
     assert open(str(tmp_path / "seq") + ".gkmqc.eval.out").read() == open(str(tmp_path / "ovl") + ".gkmqc.eval.out").read()
+    # the subsets dealt to several workers (here two on the box's one GPU, each with its own context and streams):
+    # same numbers and the same lines in the order of `pairs`
+    a3 = gkmsvm.build_parser().parse_args(["-p", POS, "-n", NEG, "-w", str(tmp_path / "farm")] + base)
+    assert gkmsvm.init_many(pairs + pairs[:1], a3, gpus=[0, 0]) == want + want[:1]
+    lines = open(str(tmp_path / "farm") + ".gkmqc.eval.out").read().splitlines()
+    assert lines[:4] == open(str(tmp_path / "seq") + ".gkmqc.eval.out").read().splitlines() and len(lines) == 5
 
 
 @pytest.mark.gpu
