@@ -19,6 +19,7 @@ def main():
     ap.add_argument("-L", type=int, default=11)
     ap.add_argument("-k", type=int, default=7)
     ap.add_argument("-d", type=int, default=3)
+    ap.add_argument("--gpus", type=int, nargs="*", default=None, help="device ordinals for init_many(gpus=...)")
     a = ap.parse_args()
     from gkmqc_amd import gkmsvm, synth
     tmp = tempfile.mkdtemp()
@@ -35,7 +36,7 @@ def main():
     t0 = time.perf_counter()
     r1 = [gkmsvm.init(p, n, a1) for p, n in pairs]
     t1 = time.perf_counter()
-    r2 = gkmsvm.init_many(pairs, a2)
+    r2 = gkmsvm.init_many(pairs, a2, gpus=a.gpus)
     t2 = time.perf_counter()
     print("%d subsets of %d + %d x %d bp (L=%d k=%d d=%d), 5-fold x %d: init %.1f ms per subset, init_many %.1f ms "
           "per subset, same results: %s" % (a.subsets, a.n, a.n, a.length, a.L, a.k, a.d, a.repeats,
