@@ -163,8 +163,7 @@ def cpu_baseline(args):
             "sample": "%s: %d+%d x %d bp, same generator and parameters, whole gkm_main_pywrapper call "
                       "(FASTA read + tree + rows), %d row threads, %.1f s wall%s"
                       % ("the WHOLE workload" if whole else "bounded sample", npos, nneg, args.length, cores, wall,
-                         "" if whole else "; the reference's pairs/s rises with N -- the full-N same-box run is "
-                         "profiles/r2_cpu_baseline_full.json (bench.py --cpu-sample 5000)")}
+                         "" if whole else "; the reference's pairs/s rises with N, so a bounded sample understates it")}
 
 
 def end_to_end(args, dev):
@@ -213,6 +212,73 @@ def end_to_end(args, dev):
     return out
 
 
+def multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus):
+    """Roofline fields of an N > 1 line from (a) SQ_INSTS_VALU of the hash-matched ONE-GPU summary of the same
+    workload and (b) what every rank measured itself.  The instructions executed per l-mer comparison do not
+    depend on which rank computes a row, so the whole job executes what the one-GPU launch executed; it is spread
+    over N GPUs for the max-over-ranks step time (kernels + collectives + assembly): frac = that / (N x peak).
+    frac_per_rank_kernel holds each rank's own kernel against ONE GPU's peak."""
+    total_cmp = sum(r["comparisons"] for r in per_rank) if per_rank else None
+    ipc = (insts * 64 / total_cmp) if insts and total_cmp else None
+    executed = (insts * 64 / sec_per_step / 1e9) if insts else None
+    out = {"achieved": executed, "frac": (executed / (PEAK_INT32_GOPS * n_gpus)) if executed else None,
+           "executed_insts_per_comparison": ipc, "peak_is": "%d GPUs x %.1f Gop/s" % (n_gpus, PEAK_INT32_GOPS)}
+    if per_rank:
+        km = [r["kernel_ms"] for r in per_rank]
+        out.update({
+            "kernel_ms_min": min(km), "kernel_ms_max": max(km), "kernel_ms_per_rank": km,
+            "comparisons_per_rank": [r["comparisons"] for r in per_rank],
+            "frac_per_rank_kernel": [(ipc * r["comparisons"] / (r["kernel_ms"] * 1e-3) / 1e9 / PEAK_INT32_GOPS)
+                                     if ipc and r["kernel_ms"] > 0 else None for r in per_rank],
+            "allgather_ms": max(r["allgather_ms"] for r in per_rank),
+            "allgather_ms_per_rank": [r["allgather_ms"] for r in per_rank],
+            "assemble_ms": max(r["assemble_ms"] for r in per_rank)})
+    return out
+
+
+def side_workload(name, dev, steps=3):
+    """A short single-GPU measurement of another workload inside the headline line (`also`): the same step
+    (row tables + Gram kernel + untile + normalise, inputs resident in HBM), `steps` timed passes after one
+    warm-up, the hot kernel's HIP-event time and the hash-gated executed-instruction fraction."""
+    import numpy as np
+    import torch
+    from gkmqc_amd import device
+    a = parse_args(["--workload", name])
+    seqs = [device.encode(x) for x in make_problem(a)]
+    n = len(seqs)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = device.GramContext(a.kernel_type, a.L, a.k, a.d, 50, 50.0, 1.0, dev.index or 0)
+    try:
+        ctx.set_sequences(seqs, stream)
+        full = torch.zeros((n, n), dtype=torch.float64, device=dev)
+        sq = torch.zeros(n, dtype=torch.float64, device=dev)
+        rows = np.arange(n)
+
+        def step():
+            ctx.gram_rows(rows, full.data_ptr(), n, None, 0, False, stream)
+            ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
+
+        step()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        kms = []
+        for _ in range(steps):
+            step()
+            torch.cuda.synchronize(dev)      # (per step, so that the kernel's own events can be read)
+            kms.append(ctx.last_kernel_ms())
+        wall = (time.perf_counter() - t0) / steps
+        comparisons = ctx.last_comparisons()
+        kern_s = float(np.mean(kms)) * 1e-3
+        pmc, src = pmc_summary(name)
+        insts = pmc["per_launch"].get("SQ_INSTS_VALU") if pmc else None
+        return {"workload": a.label, "n_sequences": n, "length": a.length_range or a.length, "L": a.L, "k": a.k, "d": a.d,
+                "steps": steps, "ms_per_step": wall * 1e3, "pairs_per_s": (n * (n - 1) / 2) / wall,
+                "kernel": ctx.last_kernel_name(), "kernel_ms": kern_s * 1e3, "comparisons_per_s": comparisons / kern_s,
+                "frac": (insts * 64 / kern_s / 1e9 / PEAK_INT32_GOPS) if insts else None, "pmc_source": src}
+    finally:
+        ctx.close()
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +298,11 @@ def parse_args(argv=None):
     ap.add_argument("--assembly", default="torch", choices=["torch", "cabi"],
                     help="N > 1: torch = one process per GPU, torch.distributed all-gather (default); "
                          "cabi = one process, gkmhip_gram_allgather (one host thread per device)")
-    ap.add_argument("--cpu-sample", type=int, default=2000, help="pos (=neg) sequences of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None,
+                    help="pos (=neg) sequences of the CPU baseline sample; default: the WHOLE workload for the headline "
+                         "(c2: 5 000 + 5 000, ~90 s on 16 cores), 2 000 + 2 000 otherwise")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the short side measurements of gkmQC's own shape (peaks) and config 5 in the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true")
     ap.add_argument("--check", action="store_true", help="compare the assembled matrix with a 1-GPU run (debug)")
@@ -246,27 +316,73 @@ def parse_args(argv=None):
             custom = True
     args.generator, args.label = w[8], ("custom (from %s)" % args.workload if custom else w[9])
     args.custom = custom
+    if args.cpu_sample is None:
+        args.cpu_sample = 5000 if (args.workload == "c2" and not custom) else 2000
     return args
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, cmd=None, timeout=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this
     process has not imported torch nor touched the GPU, and it never replaces itself), relay rank 0's
-    stdout, fail if any rank fails."""
+    stdout, fail if any rank fails.  All children are polled: the first one that exits non-zero ends the
+    others at once (a rank that dies before the process group forms would otherwise leave its peers in the
+    rendezvous until the driver's limit), and so does the overall timeout (GKM_BENCH_TIMEOUT, default 540 s).
+    Every rank's stderr is relayed line by line behind a "[rank r]" prefix."""
     import socket
+    import threading
+    timeout = float(os.environ.get("GKM_BENCH_TIMEOUT", "540")) if timeout is None else timeout
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv if cmd is None else cmd
+    procs, threads, out0 = [], [], []
+
+    def relay(stream, r):
+        for raw in iter(stream.readline, b""):
+            sys.stderr.write("[rank %d] %s" % (r, raw.decode(errors="replace")))
+            sys.stderr.flush()
+
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    line, _ = procs[0].communicate()
-    codes = [p.wait() for p in procs]
-    sys.stdout.write(line.decode())
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                             stderr=subprocess.PIPE)
+        procs.append(p)
+        threads.append(threading.Thread(target=relay, args=(p.stderr, r), daemon=True))
+        if r == 0:
+            threads.append(threading.Thread(target=lambda out=p.stdout: out0.append(out.read()), daemon=True))
+    for t in threads:
+        t.start()
+    t_end = time.time() + timeout
+    why = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad or time.time() > t_end:
+            why = ("rank %d exited with code %d" % (bad[0], codes[bad[0]])) if bad else \
+                "no result after %.0f s" % timeout
+            for p in procs:          # the exact processes started above, nothing else
+                if p.poll() is None:
+                    p.terminate()
+            t_kill = time.time() + 5
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_kill - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.1)
+    for t in threads:
+        t.join(timeout=5)
+    codes = [p.returncode for p in procs]
+    if why:
+        sys.stderr.write("bench.py: %s; the other ranks were stopped (exit codes %s)\n" % (why, codes))
+        return 1
+    sys.stdout.write(out0[0].decode() if out0 else "")
     sys.stdout.flush()
     return max(abs(c) for c in codes)
 
@@ -382,7 +498,9 @@ def run_rank(args):
         # drain of chunk c leaves idle, and its all-gather overlaps as before.
         side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if dist_on else None
 
-        def step():
+        def step(probe=None):
+            """probe: a dict that receives torch events around the collectives and the assembly (an extra,
+            untimed step after the wall-clock region: the timed steps record nothing)."""
             if not dist_on:
                 compute(0, full.data_ptr(), False)
                 ctx.normalize(full.data_ptr(), n, sq.data_ptr(), False, stream)
@@ -396,20 +514,36 @@ def run_rank(args):
                 ctx.set_scratch_slot(c & 1)     # chunks c and c+2 share a slot and a stream
                 with torch.cuda.stream(st):
                     compute(c, slab[c].data_ptr(), True, st.cuda_stream)
+                    if probe is not None:
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(st)
+                        probe.setdefault("ag0", []).append(ev)
                     if backend == "nccl":   # RCCL over xGMI, asynchronous: overlaps the next chunk's kernel
                         pending.append(dist.all_gather_into_tensor(gathered[c], slab[c], async_op=True))
                     else:                   # rehearsal through host memory
                         host = torch.empty(gathered[c].shape, dtype=gathered.dtype)
                         dist.all_gather_into_tensor(host, slab[c].cpu())
                         gathered[c].copy_(host)
+                    if probe is not None:
+                        if backend == "nccl":
+                            pending[-1].wait()  # (the probe step only: makes this stream wait for the collective)
+                        ev = torch.cuda.Event(enable_timing=True)
+                        ev.record(st)
+                        probe.setdefault("ag1", []).append(ev)
             ctx.set_scratch_slot(0)
             for w in pending:
                 w.wait()
             main_s.wait_stream(side[0])
             main_s.wait_stream(side[1])
+            if probe is not None:
+                probe["as0"] = torch.cuda.Event(enable_timing=True)
+                probe["as0"].record(main_s)
             # un-permutation + normalisation in one pass over the gathered slabs
             ctx.assemble_normalize(gathered.data_ptr(), n, slot_of_row.data_ptr(), full.data_ptr(), n, sq.data_ptr(),
                                    False, stream)
+            if probe is not None:
+                probe["as1"] = torch.cuda.Event(enable_timing=True)
+                probe["as1"].record(main_s)
 
     def barrier():
         if dist_on:
@@ -420,11 +554,13 @@ def run_rank(args):
     for _ in range(args.warmup):
         step()
     barrier()
+    allocs0 = device.load().gkmhip_allgather_alloc_count() if cabi else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    allocs_timed = (device.load().gkmhip_allgather_alloc_count() - allocs0) if cabi else 0
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -433,7 +569,12 @@ def run_rank(args):
     # dominant kernel: extra launches bracketed by HIP events on the launch stream (recorded inside
     # gkmhip_gram_rows), outside the wall-clock region
     durs, comparisons = [], 0.0
+    per_rank = None     # N > 1: what every rank measured on its own stream (kernel, collective, assembly)
     if cabi:
+        st = device.allgather_stats()   # HIP events of the last timed step, per host thread / device
+        if st:
+            per_rank = [{"kernel_ms": st["kernel_ms"][g], "comparisons": st["comparisons"][g],
+                         "allgather_ms": st["transfer_ms"][g], "assemble_ms": st["assemble_ms"][g]} for g in range(st["ranks"])]
         rows0 = np.concatenate(sharding.chunked_layout(n, args.gpus, 0, 1)[0])
         buf = torch.zeros((len(rows0), n), dtype=torch.float64, device=dev)
         for _ in range(3):
@@ -455,6 +596,17 @@ def run_rank(args):
             durs.append(ms)
     kern_ms = float(np.mean(durs))
     kname = ctx.last_kernel_name()
+    if dist_on and not cabi:
+        # one more, untimed, step with events around every collective and around the assembly
+        barrier()
+        probe = {}
+        step(probe)
+        barrier()
+        mine = {"kernel_ms": kern_ms, "comparisons": comparisons,
+                "allgather_ms": float(sum(a0.elapsed_time(a1) for a0, a1 in zip(probe["ag0"], probe["ag1"]))),
+                "assemble_ms": float(probe["as0"].elapsed_time(probe["as1"]))}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     if args.check:  # every rank recomputes the whole matrix alone and compares bit for bit
         step()
@@ -500,31 +652,42 @@ def run_rank(args):
         "dtype": "u32",
         "data": "synthetic",
         "config": {"workload": args.label + ": " + desc, "n_sequences": n, "row_sharding": sharding_note, "kernel": kname,
+                   # ranks = communicator size actually created; transport = what moved the slabs
+                   "ranks": len(per_rank) if per_rank else (args.gpus if cabi else dist.get_world_size() if dist_on else 1),
+                   "transport": (device.load().gkmhip_last_transport().decode() if cabi else
+                                 ("rccl" if backend == "nccl" else backend) if dist_on else "none"),
+                   "chunks": chunks,
                    "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GKM_")}},
     }
     if rank == 0:
         kern_s = kern_ms * 1e-3
         algorithmic = comparisons * OPS_PER_COMPARISON / kern_s / 1e9
-        pmc, pmc_src = (None, "PMC summaries are kept for the single-GPU workloads only")
-        if n_gpus == 1 and not args.custom and args.kernel == "auto":
-            pmc, pmc_src = pmc_summary(args.workload)
+        pmc, pmc_src = (None, "custom problem or forced kernel: no PMC summary applies")
+        if not args.custom and args.kernel == "auto":
+            pmc, pmc_src = pmc_summary(args.workload)     # taken on ONE GPU: the whole triangle in one launch
         insts = pmc["per_launch"].get("SQ_INSTS_VALU") if pmc else None
         traffic = pmc.get("hbm_bytes_per_launch") if pmc else None
-        executed = (insts * 64 / kern_s / 1e9) if insts else None
+        multi = None
+        if n_gpus == 1:
+            executed = (insts * 64 / kern_s / 1e9) if insts else None
+            ipc = (insts * 64 / comparisons) if insts else None
+        else:
+            multi = multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus)
+            executed, ipc, traffic = multi["achieved"], multi["executed_insts_per_comparison"], None
         peak_meas, peak_src = measured_valu_peak()
         out["roofline"] = {
             "bound": "valu",
             # EXECUTED lane-ops of the dominant kernel (rocprofv3 SQ_INSTS_VALU x 64 lanes, per launch, from the
             # committed summary taken on this very kernel source and workload) over its live duration
             "achieved": executed, "peak": PEAK_INT32_GOPS, "unit": "Gop/s",
-            "frac": (executed / PEAK_INT32_GOPS) if executed else None,
+            "frac": (executed / (PEAK_INT32_GOPS * n_gpus)) if executed else None,
             "peak_measured": peak_meas, "peak_measured_source": peak_src,
-            "frac_of_measured_peak": (executed / peak_meas) if executed and peak_meas else None,
+            "frac_of_measured_peak": (executed / (peak_meas * n_gpus)) if executed and peak_meas else None,
             "traffic": traffic, "pmc_source": pmc_src,
             "hbm_achieved_GBps": (traffic / kern_s / 1e9) if traffic else None,
             "kernel": kname, "kernel_ms": kern_ms, "comparisons_per_launch": comparisons,
             "comparisons_per_s": comparisons / kern_s,
-            "executed_insts_per_comparison": (insts * 64 / comparisons) if insts else None,
+            "executed_insts_per_comparison": ipc,
             # the op model of SURVEY.md §8(d) (6 int32 ops per l-mer comparison): what a comparison-by-comparison
             # kernel would have to execute; the bit-sliced kernel executes ~10x fewer, so this "fraction" exceeds 1
             "algorithmic_ops_per_comparison": OPS_PER_COMPARISON,
@@ -533,10 +696,29 @@ def run_rank(args):
                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); null when the committed PMC summary was not taken on this "
                     "kernel source + workload. kernel_ms: HIP events on the launch stream. HBM traffic is incidental.",
         }
-        # the two side measurements must never cost the line itself: a failure is reported in their place
+        if n_gpus > 1:
+            rf = out["roofline"]
+            rf.update(multi)
+            rf["note"] += (" N > 1: achieved = the one-GPU launch's executed lane-ops / the max-over-ranks step time (kernels, "
+                           "collectives, assembly), frac = that / (N x peak); kernel_ms, comparisons_per_launch and "
+                           "comparisons_per_s are rank 0's own kernel; allgather_ms = sum over the %d chunks of the "
+                           "collective's time on its stream (HIP events), which overlaps the next chunk's kernel." % chunks)
+            if cabi:
+                rf["allgather_hipmalloc_calls_in_timed_region"] = allocs_timed
+        # the side measurements must never cost the line itself: a failure is reported in their place
+        if n_gpus == 1 and args.workload == "c2" and not args.custom and not args.no_also:
+            # gkmQC's own shape (bin/gkmqc.py:150-154,181-185: 600 bp, wgkm L=10 k=6 d=3) and config 5 (ragged,
+            # L=12 d=4), three steps each, so that their numbers are timed by whoever runs the headline line
+            try:
+                ctx.close()
+                full = None
+                torch.cuda.empty_cache()
+                out["also"] = {name: side_workload(name, dev) for name in ("peaks", "c5")}
+            except Exception as e:   # noqa: BLE001
+                out["also"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if n_gpus == 1 and not args.no_end_to_end:
             ctx.close()
-            del full
+            full = None
             torch.cuda.empty_cache()
             try:
                 out["end_to_end"] = end_to_end(args, dev)
@@ -545,6 +727,14 @@ def run_rank(args):
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
+                cb = out["cpu_baseline"]
+                if cb.get("headline_workload") and cb.get("value"):
+                    # BASELINE.md holds no published number for this metric (the reference ships none); the one
+                    # baseline there is: its own CPU path on this box's host cores, same files, same N
+                    out["vs_baseline"] = out["value"] / cb["value"]
+                    out["vs_baseline_is"] = ("value / cpu_baseline.value: the reference's CPU path (%s, %d cores) on the "
+                                             "same box and the same workload; BASELINE.md has no published number"
+                                             % (cb["kind"], cb["cores"]))
             except Exception as e:   # noqa: BLE001
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out), file=real_stdout, flush=True)

@@ -503,16 +503,26 @@ GKM_HD HitValue resolve_hit_packed(int b, int w, int delta, int strand, uint32_t
     return r;
 }
 
-/* hit record: w (6 bits) | delta << 6 (11) | strand << 17 | source lane << 18 (6) | bit << 24 (5) */
-GKM_HD uint32_t pack_meta(int delta, int w, int strand)
+/* Origin word of a hit record.  The layout is chosen for the instruction count of the trip that consumes it, priced
+ * with the issue rates measured on gfx950 (tools/valu_ops.hip, profiles/r3_valu_ops.txt: v_and / v_or / v_add / v_sub /
+ * v_xor / v_lshrrev / v_lshlrev by a constant / v_bitop3 issue every ~2.2 cycles per SIMD, everything else -- v_bfe,
+ * v_mad_u32_u24, v_min, v_sad, v_alignbit, v_ffbl, v_bcnt, compares, SDWA, any SGPR operand -- every ~4.2):
+ *   bits  0..3   word index w within the shift (0..W-1; a trip adds the word's offset in its group)       ms & 15
+ *   bit   4      strand (0 forward, 1 reverse complement): (ms >> 2) & 4 is the byte offset of the strand's word
+ *                in the interleaved column image in LDS
+ *   bit   5      strand & [the column has an even number of l-mers]: the reverse strand's weights are the forward
+ *                ones mirrored, wt_rc[q] = wt[nB-1-q] = wd[|q + even - nB/2|] (libgkm.c:924)
+ *   bits  7..12  source lane; ms & 0x1F80 is the byte offset of that lane's packed positions (128 bytes per lane)
+ *   bits 21..31  shift delta (0..2046): ms >> 21 */
+constexpr uint32_t META_LANE_SHIFT = 7;
+GKM_HD uint32_t pack_meta(int delta, int w, int strand, int even_adj = 0)
 {
-    return (uint32_t)w | ((uint32_t)delta << 6) | ((uint32_t)strand << 17);
+    return (uint32_t)w | ((uint32_t)strand << 4) | ((uint32_t)(strand & even_adj) << 5) | ((uint32_t)delta << 21);
 }
-GKM_HD int rec_w(uint32_t r) { return (int)(r & 63u); }
-GKM_HD int rec_delta(uint32_t r) { return (int)((r >> 6) & 2047u); }
-GKM_HD int rec_strand(uint32_t r) { return (int)((r >> 17) & 1u); }
-GKM_HD int rec_lane(uint32_t r) { return (int)((r >> 18) & 63u); }
-GKM_HD int rec_bit(uint32_t r) { return (int)(r >> 24); }
+GKM_HD int rec_w(uint32_t r) { return (int)(r & 15u); }
+GKM_HD int rec_delta(uint32_t r) { return (int)(r >> 21); }
+GKM_HD int rec_strand(uint32_t r) { return (int)((r >> 4) & 1u); }
+GKM_HD int rec_lane(uint32_t r) { return (int)((r >> META_LANE_SHIFT) & 63u); }
 
 } /* namespace gkmbs */
 #endif

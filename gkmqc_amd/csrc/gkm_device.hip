@@ -319,14 +319,18 @@ __global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *_
     }
 }
 
-/* grid (sequence*2+strand); threads over the words of the strand's 2-bit packed copy (gkm_bitslice.h pk_word) */
+/* grid (sequence*2+strand); threads over the words of the strand's 2-bit packed copy (gkm_bitslice.h pk_word).
+ * The two strands of a sequence are interleaved word by word, colpk[(seq * pkw + x) * 2 + strand]: the hot kernel
+ * copies the 2 * pkw words of a column to LDS as they are, and a hit reads words x and x + 1 of its strand at byte
+ * offset (x * 8) | (strand * 4) -- the strand costs the address one OR instead of a multiply-add */
 __global__ void k_pack_strands(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int pkw,
                                uint32_t *__restrict__ colpk)
 {
     const int e = blockIdx.x, s = e >> 1, strand = e & 1;
     const uint8_t *seq = codes + off[s];
     const int T = (int)(off[s + 1] - off[s]);
-    for (int x = threadIdx.x; x < pkw; x += blockDim.x) colpk[(size_t)e * pkw + x] = gkmbs::pk_word(seq, T, strand, x);
+    for (int x = threadIdx.x; x < pkw; x += blockDim.x)
+        colpk[((size_t)s * pkw + x) * 2 + strand] = gkmbs::pk_word(seq, T, strand, x);
 }
 
 /* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
@@ -345,7 +349,8 @@ __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__r
 /* Packed lanes (gkm_pack.h): grid (tile, plane); 64 threads = the tile's lanes; output layout
  * [tile][plane][w][lane].  desc holds MAX_PIECES x {row, b0, nb, p0, cnt} per lane (nb = 0: unused).
  * plane 3: the lane's positions 2-bit packed for the hit path, rowpk[(tile*64 + lane) * rpw + x]
- * (16 positions per word, position i = bit row i / W, word i % W of the bit planes). */
+ * (16 positions per word, position i = bit row i / W, word i % W of the bit planes; rpw = 32 words = 128 bytes
+ * per lane, of which 32 W / 16 + 1 are used). */
 __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
                                   const int *__restrict__ desc, int W, uint32_t *__restrict__ planes,
                                   uint32_t *__restrict__ rowpk, int rpw)
@@ -355,7 +360,7 @@ __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64
     if (plane == 3) {
         for (int x = 0; x < rpw; x++) {
             uint32_t v = 0u;
-            for (int k = 0; k < gkmpack::MAX_PIECES; k++) {
+            for (int k = 0; k < gkmpack::MAX_PIECES && x * 16 < 32 * W; k++) { /* (words past the lane's positions: 0) */
                 const int row = d[k * 5 + 0], b0 = d[k * 5 + 1], nb = d[k * 5 + 2], p0 = d[k * 5 + 3];
                 if (nb <= 0) continue;
                 const uint8_t *seq = codes + off[row];
@@ -404,7 +409,7 @@ struct BsArgs {
     const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
     const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
     const uint32_t *rowpk;      /* [tile*64 + lane][rpw] the lanes' positions, 2-bit packed (k_build_rowplanes) */
-    const uint32_t *colpk;      /* [seq*2 + strand][pkw] 2-bit packed strands                                 */
+    const uint32_t *colpk;      /* [seq][pkw][strand] 2-bit packed strands, the two strands interleaved        */
     const uint32_t *wd32;       /* distance-indexed positional weights (bytes), wd_words dwords               */
     int rpw, pkw, wd_words;
     const uint32_t *sb;
@@ -450,6 +455,15 @@ __device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x)
 {
     uint32_t r;
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* 2 x as an addition: on gfx950 v_lshlrev_b32 issues at HALF the rate of v_add_u32 (tools/valu_ops.hip), and hipcc
+ * turns x + x back into a shift */
+__device__ __forceinline__ uint32_t twice(uint32_t x)
+{
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
     return r;
 }
 
@@ -589,17 +603,21 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         my_slot4 = A.lane_piece[(size_t)(tile * 64 + lane) * 2];
         my_c0b = A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1];
     }
-    const uint32_t lane_tag = (uint32_t)lane << 18;
+    const uint32_t lane_tag = (uint32_t)lane << META_LANE_SHIFT, lane4 = (uint32_t)lane << 2;
     const int pkw = A.pkw;
-    /* the weight table sits at the start of the dynamic LDS: its address is a constant of the kernel and
-     * folds into the offset field of the byte reads */
-    uint32_t *const s_col = s_dyn + A.wd_words;
-    for (int x = lane; x < A.wd_words; x += 64) s_dyn[x] = A.wd32[x];
-    const uint32_t lane4 = (uint32_t)lane << 2, pkw4 = (uint32_t)pkw * 4u;
+    /* dynamic LDS: the column's two packed strands first, interleaved word by word (their address is then a constant
+     * of the kernel and folds into the offset field of the reads), the weight table behind them (its offset rides in
+     * the third operand of the v_sad_u32 that forms the index) */
+    uint32_t *const s_col = s_dyn;
+    /* byte offset of the weight table, kept in a VGPR: the column-side index |q - centre| + wbase would otherwise name
+     * two SGPRs in one v_sad_u32 (one is the limit) and cost a v_mov per hit */
+    uint32_t wbase;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(wbase) : "s"((uint32_t)pkw * 8u));
+    for (int x = lane; x < A.wd_words; x += 64) s_dyn[2 * pkw + x] = A.wd32[x];
     /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
-     * base instead of a 64-bit address computed per lane) */
+     * base instead of a 64-bit address computed per lane); 128 bytes per lane, so that the lane field of a
+     * record's origin word IS the lane's byte offset */
     const char *const rowpk_tile = (const char *)(A.rowpk + (size_t)tile * 64 * A.rpw);
-    const uint32_t rpw4 = (uint32_t)A.rpw * 4u;
 
     for (int j = j0; j < j1; j++) {
         const int T = A.len[j];
@@ -607,8 +625,10 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         const uint32_t rcpT = mod_magic((uint32_t)T);
         for (int x = lane; x < 2 * pkw; x += 64) s_col[x] = A.colpk[(size_t)j * 2 * pkw + x];
         /* weight of a column l-mer q: forward strand wd[|nB/2 - q|]; reverse strand wt_rc[q] = wt[nB-1-q]
-         * (libgkm.c:924) = wd[|nB/2 - (nB-1-q)|] = wd[|q - (nB/2 - [nB even])|] */
-        const uint32_t ccen = (uint32_t)(nB / 2), ceven = (nB & 1) ? 0u : 1u;
+         * (libgkm.c:924) = wd[|nB/2 - (nB-1-q)|] = wd[|q + [nB even] - nB/2|]; the [nB even] of the reverse strand
+         * travels in bit 5 of the record's origin word (pack_meta) */
+        const uint32_t ccen = (uint32_t)(nB / 2);
+        const int ceven = (nB & 1) ? 0 : 1;
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
@@ -617,45 +637,50 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         /* One hit -> accl[m][row slot] += wa * wb.  (meta + sel, bit) name the row lane r, the lane position
          * i0 = bit*W + w of the window, the shift and the strand; lane and bit row name the piece (gkm_pack.h),
          * the piece names the row slot and c0, which makes |c0 - i0| the row l-mer's distance to its sequence's
-         * centre l-mer (libgkm.c:912-925 depends on nothing else).  Written for the instruction count -- the
-         * kernel is bound by VALU issue, and a trip's ~60 instructions per 64 hits are a sixth of all it
-         * executes: 24-bit multiply-adds, |a - b| + c as one v_sad_u32, funnel shifts that mask their own shift
-         * count, the weight table at a constant LDS offset.  Same arithmetic as resolve_hit_packed
-         * (gkm_bitslice.h), which the CPU tests run against the oracle. */
+         * centre l-mer (libgkm.c:912-925 depends on nothing else).  Written for the ISSUE COST -- the kernel is
+         * bound by VALU issue, and on gfx950 only the plain two-operand integer operations and v_bitop3_b32 issue
+         * at the full rate; v_bfe, v_mad_u32_u24, v_min, v_sad, v_alignbit, v_ffbl, v_bcnt, compares, SDWA and
+         * anything with an SGPR operand take twice as long (tools/valu_ops.hip).  Hence the layout of the origin
+         * word (gkm_bitslice.h pack_meta: fields that are masked in place or shifted out of the top), 128 bytes per
+         * lane of packed positions, the column's strands interleaved word by word, (a & const) | b as one
+         * v_bitop3_b32, the weight table's LDS offset as the third operand of the v_sad_u32 that forms the index.
+         * Same arithmetic as resolve_hit_packed (gkm_bitslice.h), which the CPU tests run against the oracle. */
         auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
             if (VARIANT & 16) { atomicAdd(&accl[rec_lane(ms)], ms | (bit << 24)); return; } /* timing: no table reads */
-            const uint32_t r = (ms >> 18) & 63u;
-            const uint32_t smask = (uint32_t)((int32_t)(ms << 14) >> 31); /* all ones on the reverse strand (v_bfe_i32) */
-            const int k = PACKED ? piece_of_bitrow(lmask[PACKED ? r : 0], (int)bit) : 0;
+            const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
+            const int k = PACKED ? piece_of_bitrow(*(const uint32_t *)((const char *)lmask + (PACKED ? (lane128 >> 5) : 0u)), (int)bit) : 0;
             uint32_t slot4, c0b; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
             if (PACKED) {
-                const uint32_t lp = lpiece[r * NP + k];
+                static_assert(!PACKED || NP == 4, "lpiece is addressed as lane * 16 + piece * 4");
+                const uint32_t lp = *(const uint32_t *)((const char *)lpiece + ((lane128 >> 3) + ((uint32_t)k << 2)));
                 slot4 = lp & 0xFFFFu;
                 c0b = lp >> 16;
             } else if (BPERM) {
                 slot4 = pslot4;
                 c0b = pc0b;
             } else {
-                slot4 = lpiece[r * 2];
-                c0b = lpiece[r * 2 + 1];
+                const uint32_t *lp2 = (const uint32_t *)((const char *)lpiece + (lane128 >> 4));
+                slot4 = lp2[0];
+                c0b = lp2[1];
             }
-            const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 63u);
-            const uint32_t x = i0 + ((ms >> 6) & 2047u);
+            const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 15u);
+            const uint32_t x = i0 + (ms >> 21);
             uint32_t q;
             if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
             else q = mod_small(x, (uint32_t)T, rcpT);
             /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
             if ((int)q < nB) {
+                /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
                 const uint32_t *rw = (VARIANT & 512) /* timing: the row words from (arbitrary) LDS instead of global memory */
-                    ? (const uint32_t *)((const char *)s_list + ((__umul24(r, rpw4) + ((i0 >> 2) & ~3u)) & 0x7F8u))
-                    : (const uint32_t *)(rowpk_tile + (__umul24(r, rpw4) + ((i0 >> 2) & ~3u)));
-                const uint32_t *cw = (const uint32_t *)((const char *)s_col + ((smask & pkw4) + ((q >> 2) & ~3u)));
+                    ? (const uint32_t *)((const char *)s_list + ((lane128 + ((i0 >> 2) & ~3u)) & 0x7F8u))
+                    : (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+                const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, (ms >> 2) & 4u));
                 const uint8_t *wdb = (const uint8_t *)s_dyn;
-                const uint32_t wa = wdb[__usad(c0b, i0 + 2048u, 0u)];
-                const uint32_t wb = wdb[__usad(q, ccen - (smask & ceven), 0u)];
+                const uint32_t wa = wdb[__usad(c0b, i0 | 2048u, wbase)];
+                const uint32_t wb = wdb[__usad(q + ((ms >> 5) & 1u), ccen, wbase)];
                 /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
-                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], i0 << 1);
-                const uint32_t eb = __builtin_amdgcn_alignbit(cw[1], cw[0], q << 1);
+                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
+                const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
                 const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
                 if (VARIANT & 128) { asm volatile("" ::"v"(m), "v"(wa), "v"(wb), "v"(slot4)); return; } /* timing: no accumulate */
                 if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 */
@@ -663,6 +688,54 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             }
         };
 
+        /* one trip over the `c` records at the head of the ring (PARTIAL: c < BS_TRIP, the last trip of a column) */
+        auto trip = [&](auto partial_tag, int c) {
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            static_assert(BS_CAP_POW2, "ring offsets wrap with one AND");
+            const char *const at = (const char *)s_list + ((((uint32_t)s_hd << 2) + lane4) & (uint32_t)(BS_CAP * 4 - 1));
+            uint32_t h[BS_GRP];
+            /* (every ring slot is readable: the lanes past the end of a short, final trip are
+             * cleared afterwards instead of being masked out of the loads) */
+#pragma unroll
+            for (int g = 0; g < BS_GRP; g++) h[g] = *(const uint32_t *)(at + g * BS_CAP * 4);
+            const uint32_t meta = *(const uint32_t *)(at + BS_GRP * BS_CAP * 4);
+            if (PARTIAL) {
+#pragma unroll
+                for (int g = 0; g < BS_GRP; g++) h[g] = (lane < c) ? h[g] : 0u;
+            }
+            uint32_t first = ffbl_or_ones(h[0]), total = 0u;
+#pragma unroll
+            for (int g = 1; g < BS_GRP; g++) first = min(first, ffbl_or_ones(h[g]) | (uint32_t)(g << 5));
+#pragma unroll
+            for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
+            const uint32_t sel = first >> 5, bit = first & 31u;
+            const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 4 bits */
+            uint32_t pslot4 = 0u, pc0b = 0u;
+            if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
+                const int from = (int)((ms >> (META_LANE_SHIFT - 2)) & 0xFCu); /* source lane * 4 */
+                pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
+                pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
+            }
+            /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
+            if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
+            s_hd = (int)ring((uint32_t)(s_hd + c));
+            s_n -= c;
+            const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
+                                                           : __ballot(total > 1u);
+            if (more) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                if (total > 1u) {
+                    char *const to = (char *)s_list + (((rank << 2) + ((uint32_t)(s_hd + s_n) << 2)) & (uint32_t)(BS_CAP * 4 - 1));
+#pragma unroll
+                    for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
+                    *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
+                    if (VARIANT & 256) *(volatile uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)) = 0u; /* timing: plain store, the word is dropped */
+                    else atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
+                }
+                s_n += (int)__popcll(more);
+            }
+        };
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
          * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
          * again.  Fewer than one trip's worth of records waits in the ring; the last call of a column
@@ -673,52 +746,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
         auto trips = [&](bool final) {
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
-            while (s_n >= BS_TRIP || (final && s_n > 0)) {
-                const int c = min(s_n, BS_TRIP);
-                static_assert(BS_CAP_POW2, "ring offsets wrap with one AND");
-                const char *const at = (const char *)s_list + ((((uint32_t)s_hd << 2) + lane4) & (uint32_t)(BS_CAP * 4 - 1));
-                uint32_t h[BS_GRP];
-                /* (every ring slot is readable: the lanes past the end of a short, final trip are
-                 * cleared afterwards instead of being masked out of the loads) */
-#pragma unroll
-                for (int g = 0; g < BS_GRP; g++) h[g] = *(const uint32_t *)(at + g * BS_CAP * 4);
-                const uint32_t meta = *(const uint32_t *)(at + BS_GRP * BS_CAP * 4);
-                if (c < BS_TRIP) { /* wave-uniform */
-#pragma unroll
-                    for (int g = 0; g < BS_GRP; g++) h[g] = (lane < c) ? h[g] : 0u;
+            while (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
+            if (final)
+                while (s_n > 0) {
+                    if (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
+                    else trip(std::true_type(), s_n);
                 }
-                uint32_t first = ffbl_or_ones(h[0]), total = 0u;
-#pragma unroll
-                for (int g = 1; g < BS_GRP; g++) first = min(first, ffbl_or_ones(h[g]) | (uint32_t)(g << 5));
-#pragma unroll
-                for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
-                const uint32_t sel = first >> 5, bit = first & 31u;
-                const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 6 bits */
-                uint32_t pslot4 = 0u, pc0b = 0u;
-                if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
-                    const int from = (int)((ms >> 16) & 0xFCu); /* source lane * 4 */
-                    pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
-                    pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
-                }
-                if (total) resolve(ms, bit, pslot4, pc0b);
-                s_hd = (int)ring((uint32_t)(s_hd + c));
-                s_n -= c;
-                const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
-                                                               : __ballot(total > 1u);
-                if (more) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
-                    if (total > 1u) {
-                        char *const to = (char *)s_list + (((rank << 2) + ((uint32_t)(s_hd + s_n) << 2)) & (uint32_t)(BS_CAP * 4 - 1));
-#pragma unroll
-                        for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
-                        *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
-                        if (VARIANT & 256) *(volatile uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)) = 0u; /* timing: plain store, the word is dropped */
-                        else atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
-                    }
-                    s_n += (int)__popcll(more);
-                }
-            }
         };
 
         for (int strand = 0; strand < 2; strand++) {
@@ -749,7 +782,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                     if (d0 + u < T) {
                         uint32_t hit[W];
                         window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, (const uint32_t *)nullptr, hit);
-                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand);
+                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand, ceven);
 #pragma unroll
                         for (int w0 = 0; w0 < W; w0 += BS_GRP) {
                             if ((VARIANT & 3) == 1) {
@@ -949,7 +982,12 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipSetDevice(ctx->device));
     const int L = ctx->L;
     const int weighted = (wdist != nullptr && wdist_len > 0) ? 1 : 0;
-    ctx->n = n;
+    /* a context may be reused for another set of sequences (gkmsvm.init_many keeps one per device): every
+     * per-sequence table of the previous set is stale from here on, BEFORE anything below sizes itself by them */
+    ctx->have_lmers = false;
+    ctx->have_sb = false;
+    ctx->have_colpk = false;
+    ctx->n = 0;
     ctx->weighted = weighted;
     ctx->h_len.resize((size_t)n);
     ctx->h_lmoff.resize((size_t)n + 1);
@@ -966,6 +1004,7 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
         ctx->h_cum_n[(size_t)i + 1] = ctx->h_cum_n[(size_t)i] + (double)(len - L + 1);
         ctx->maxlen = std::max(ctx->maxlen, (int)len);
     }
+    ctx->n = n;
     if (weighted && (wdist_len <= (ctx->maxlen - L + 1) / 2 || wdist_len > WD_LDS))
         return set_err_msg("distance weight table must cover 0..max(n)/2 and hold at most 1024 entries", 3);
     const size_t total = (size_t)offsets[n];
@@ -991,9 +1030,6 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
      * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
     HIPCHK(hipStreamSynchronize(stream));
-    ctx->have_lmers = false;
-    ctx->have_sb = false;
-    ctx->have_colpk = false;
     return 0;
 }
 
@@ -1132,6 +1168,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
         const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
         bs_kernel_t bs = !packed ? pick_bitslice<10, 0>(L, d) : slots == 64 ? pick_bitslice<10, 1>(L, d) : bs10;
+        /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
+        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t);
         bool bperm = false;
         if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
@@ -1146,7 +1184,6 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                 bperm = true;
             if (bperm) bs = bsp;
         }
-        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
         std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)LPW, 0u);
@@ -1199,13 +1236,18 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
-        const int rpw = 32 * W / 16 + 1; /* words of a lane's packed positions (+1: the hit path reads two) */
+        /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
+         * so that the lane field of a record's origin word is the lane's byte offset (gkm_bitslice.h pack_meta) */
+        const int rpw = 32;
+        static_assert(32 * 10 / 16 + 1 <= 32, "a lane's packed positions fit 128 bytes");
         PinBuf *hb = pin_acquire(blob.size());
         if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
         if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) ||
             scr.rowpk.ensure(nl * (size_t)rpw, true) ||
-            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS, true)))
+            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS, true))) {
+            pin_release(hb);
             return 4;
+        }
         /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
          * may still be reading it after this function has returned and freed it */
         memcpy(hb->p, blob.data(), blob.size());

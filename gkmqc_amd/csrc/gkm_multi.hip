@@ -41,6 +41,7 @@ typedef int ncclResult_t;                  /* ncclSuccess == 0 */
 enum { GKM_NCCL_FLOAT64 = 8 };             /* ncclDataType_t: ncclDouble / ncclFloat64 */
 typedef ncclResult_t (*fn_CommInitAll)(ncclComm_t *, int, const int *);
 typedef ncclResult_t (*fn_CommDestroy)(ncclComm_t);
+typedef ncclResult_t (*fn_CommAbort)(ncclComm_t);
 typedef ncclResult_t (*fn_AllGather)(const void *, void *, size_t, int, ncclComm_t, hipStream_t);
 typedef const char *(*fn_GetErrorString)(ncclResult_t);
 
@@ -50,6 +51,7 @@ struct Rccl {
     void *handle = nullptr;
     fn_CommInitAll CommInitAll = nullptr;
     fn_CommDestroy CommDestroy = nullptr;
+    fn_CommAbort CommAbort = nullptr; /* optional: frees a communicator whose collective never completed */
     fn_AllGather AllGather = nullptr;
     fn_GetErrorString GetErrorString = nullptr;
     std::vector<int> devs;         /* device list of the cached clique */
@@ -72,6 +74,7 @@ bool rccl_load()
     if (!g_rccl.handle) { g_rccl.why = std::string("cannot load RCCL: ") + dlerror(); return false; }
     g_rccl.CommInitAll = (fn_CommInitAll)dlsym(g_rccl.handle, "ncclCommInitAll");
     g_rccl.CommDestroy = (fn_CommDestroy)dlsym(g_rccl.handle, "ncclCommDestroy");
+    g_rccl.CommAbort = (fn_CommAbort)dlsym(g_rccl.handle, "ncclCommAbort");
     g_rccl.AllGather = (fn_AllGather)dlsym(g_rccl.handle, "ncclAllGather");
     g_rccl.GetErrorString = (fn_GetErrorString)dlsym(g_rccl.handle, "ncclGetErrorString");
     if (!g_rccl.CommInitAll || !g_rccl.CommDestroy || !g_rccl.AllGather || !g_rccl.GetErrorString) {
@@ -82,10 +85,10 @@ bool rccl_load()
     return true;
 }
 
-void rccl_drop_comms()
+void rccl_drop_comms(bool abort = false)
 {
     for (ncclComm_t c : g_rccl.comms)
-        if (c) (void)g_rccl.CommDestroy(c);
+        if (c) (void)((abort && g_rccl.CommAbort) ? g_rccl.CommAbort(c) : g_rccl.CommDestroy(c));
     g_rccl.comms.clear();
     g_rccl.devs.clear();
 }
@@ -142,6 +145,44 @@ private:
     bool acc_ = false, result_ = false;
 };
 
+/* Everything a rank needs besides its context, kept from call to call (bin/gkmqc.py asks for ~20 matrices of the
+ * same size per run): the slab of this rank's rows, the gathered slabs of all ranks, the gather index, the self
+ * norms, three streams and the events.  hipMalloc / hipFree synchronise the whole device, so a call that allocated
+ * ~1.7 GB and freed it again paid for that beside a ~10 ms kernel on 8 GPUs.  Keyed by (device, n, ranks, chunks);
+ * rebuilt when any of them changes, freed by gkmhip_release_comms(). */
+struct RankCache {
+    int dev = -1, n = 0, G = 0, chunks = 0, pc = 0;
+    double *slab = nullptr, *gathered = nullptr, *sq = nullptr;
+    int64_t *d_slot = nullptr;
+    hipStream_t sk[2] = {nullptr, nullptr}, sc = nullptr;
+    std::vector<hipEvent_t> ready;          /* [chunk] slab complete (no timing: waited for by peers) */
+    std::vector<hipEvent_t> k0, k1, a0, a1; /* [chunk] timing: kernel of the chunk, transfer of the chunk */
+    hipEvent_t n0 = nullptr, n1 = nullptr;  /* timing: un-permute + normalise */
+};
+RankCache g_cache[64];
+std::atomic<long> g_allocs{0}; /* hipMalloc calls made by this file (tests: the second call of a kind makes none) */
+
+void cache_release(RankCache &R)
+{
+    if (R.dev < 0) return;
+    (void)hipSetDevice(R.dev);
+    if (R.slab) (void)hipFree(R.slab);
+    if (R.gathered) (void)hipFree(R.gathered);
+    if (R.sq) (void)hipFree(R.sq);
+    if (R.d_slot) (void)hipFree(R.d_slot);
+    for (auto *v : {&R.ready, &R.k0, &R.k1, &R.a0, &R.a1}) {
+        for (hipEvent_t e : *v)
+            if (e) (void)hipEventDestroy(e);
+        v->clear();
+    }
+    if (R.n0) (void)hipEventDestroy(R.n0);
+    if (R.n1) (void)hipEventDestroy(R.n1);
+    for (int i = 0; i < 2; i++)
+        if (R.sk[i]) (void)hipStreamDestroy(R.sk[i]);
+    if (R.sc) (void)hipStreamDestroy(R.sc);
+    R = RankCache();
+}
+
 struct Call {
     int G = 0, n = 0, chunks = 1, pc = 0, symmetric = 0;
     int64_t ld = 0;
@@ -149,13 +190,17 @@ struct Call {
     gkmhip_ctx **ctxs = nullptr;
     double **K = nullptr;
     std::vector<int> devs;
-    std::vector<double *> slab, gathered;               /* per rank, on its device */
-    std::vector<std::vector<hipEvent_t>> ready;         /* [rank][chunk]: that slab is complete */
     std::vector<int64_t> slot_of_row;
     std::vector<std::string> err;
     std::atomic<int> failed{0};
+    std::atomic<int> stuck{0}; /* a collective was enqueued by some ranks only: do not wait for it */
     HostBarrier *bar = nullptr;
 };
+
+/* what the most recent call measured, per rank (gkmhip_allgather_stats) */
+struct RankStats { double kernel_ms = 0, transfer_ms = 0, assemble_ms = 0, comparisons = 0; };
+std::vector<RankStats> g_stats;
+int g_stats_chunks = 0;
 
 #define MCHK(expr)                                                                              \
     do {                                                                                        \
@@ -171,58 +216,88 @@ void rank_thread(Call &C, int g)
     bool fail = false;
     const int G = C.G, n = C.n, chunks = C.chunks, pc = C.pc, dev = C.devs[(size_t)g];
     const size_t slab_elems = (size_t)pc * (size_t)n;
-    hipStream_t sk[2] = {nullptr, nullptr}, sc = nullptr;
-    int64_t *d_slot = nullptr;
-    double *sq = nullptr;
+    RankCache &R = g_cache[g];
     const std::vector<std::vector<int>> parts = gkmshard::chunked_layout(n, G, g, chunks);
 
-    /* ---- phase 0: buffers, streams, events ---- */
+    /* ---- phase 0: buffers, streams, events (kept from the previous call of the same shape) ---- */
     MCHK(hipSetDevice(dev));
-    if (!fail) MCHK(hipMalloc((void **)&C.slab[(size_t)g], (size_t)chunks * slab_elems * sizeof(double)));
-    if (!fail) MCHK(hipMalloc((void **)&C.gathered[(size_t)g], (size_t)chunks * (size_t)G * slab_elems * sizeof(double)));
-    if (!fail) MCHK(hipMalloc((void **)&d_slot, (size_t)n * sizeof(int64_t)));
-    if (!fail) MCHK(hipMalloc((void **)&sq, (size_t)n * sizeof(double)));
-    for (int i = 0; i < 2 && !fail; i++) MCHK(hipStreamCreateWithFlags(&sk[i], hipStreamNonBlocking));
-    if (!fail) MCHK(hipStreamCreateWithFlags(&sc, hipStreamNonBlocking));
-    for (int c = 0; c < chunks && !fail; c++) MCHK(hipEventCreateWithFlags(&C.ready[(size_t)g][(size_t)c], hipEventDisableTiming));
-    if (!fail) MCHK(hipMemcpy(d_slot, C.slot_of_row.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    if (!fail && !(R.dev == dev && R.n == n && R.G == G && R.chunks == chunks && R.pc == pc)) {
+        cache_release(R);
+        R.dev = dev; R.n = n; R.G = G; R.chunks = chunks; R.pc = pc;
+        auto dmalloc = [&](void **p, size_t bytes) { g_allocs++; return hipMalloc(p, bytes); };
+        MCHK(dmalloc((void **)&R.slab, (size_t)chunks * slab_elems * sizeof(double)));
+        if (!fail) MCHK(dmalloc((void **)&R.gathered, (size_t)chunks * (size_t)G * slab_elems * sizeof(double)));
+        if (!fail) MCHK(dmalloc((void **)&R.d_slot, (size_t)n * sizeof(int64_t)));
+        if (!fail) MCHK(dmalloc((void **)&R.sq, (size_t)n * sizeof(double)));
+        for (int i = 0; i < 2 && !fail; i++) MCHK(hipStreamCreateWithFlags(&R.sk[i], hipStreamNonBlocking));
+        if (!fail) MCHK(hipStreamCreateWithFlags(&R.sc, hipStreamNonBlocking));
+        R.ready.assign((size_t)chunks, nullptr);
+        for (auto *v : {&R.k0, &R.k1, &R.a0, &R.a1}) v->assign((size_t)chunks, nullptr);
+        for (int c = 0; c < chunks && !fail; c++) {
+            MCHK(hipEventCreateWithFlags(&R.ready[(size_t)c], hipEventDisableTiming));
+            for (auto *v : {&R.k0, &R.k1, &R.a0, &R.a1})
+                if (!fail) MCHK(hipEventCreate(&(*v)[(size_t)c]));
+        }
+        if (!fail) MCHK(hipEventCreate(&R.n0));
+        if (!fail) MCHK(hipEventCreate(&R.n1));
+        if (!fail) MCHK(hipMemcpy(R.d_slot, C.slot_of_row.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (fail) { /* half-built: nothing of it may be taken for a cache hit later */
+            const std::string keep = C.err[(size_t)g];
+            cache_release(R);
+            C.err[(size_t)g] = keep;
+        }
+    }
     if (fail) C.failed = 1;
     C.bar->wait();
+    hipStream_t *sk = R.sk, sc = R.sc;
+    RankStats st_out;
 
     /* ---- phase 1: per chunk, the Gram kernel of this rank's rows, then the all-gather of the slab ---- */
     for (int c = 0; c < chunks; c++) {
         const bool go = !C.failed.load();
-        double *my_slab = go ? C.slab[(size_t)g] + (size_t)c * slab_elems : nullptr;
+        double *my_slab = go ? R.slab + (size_t)c * slab_elems : nullptr;
         if (go) {
             hipStream_t st = sk[c & 1];
             const std::vector<int> &rows = parts[(size_t)c];
+            MCHK(hipEventRecord(R.k0[(size_t)c], st));
             if (!rows.empty()) {
                 int rc = gkmhip_set_scratch_slot(C.ctxs[g], c & 1);
                 if (!rc) rc = gkmhip_gram_rows(C.ctxs[g], rows.data(), (int)rows.size(), 1, my_slab, n, nullptr, 0, st);
                 if (rc && !fail) { fail = true; C.err[(size_t)g] = gkmhip_last_error(); }
+                if (!rc) st_out.comparisons += gkmhip_last_comparisons(C.ctxs[g]);
             }
-            MCHK(hipEventRecord(C.ready[(size_t)g][(size_t)c], st));
+            MCHK(hipEventRecord(R.k1[(size_t)c], st));
+            MCHK(hipEventRecord(R.ready[(size_t)c], st));
             if (fail) C.failed = 1;
         }
         if (C.use_rccl) {
             /* every rank must enter the collective or none: a rank whose launch failed would leave the others
              * waiting in the all-gather for ever, so the ranks agree on the host first */
             if (!C.bar->wait(C.failed.load() != 0)) {
-                MCHK(hipStreamWaitEvent(sc, C.ready[(size_t)g][(size_t)c], 0));
-                const ncclResult_t r = g_rccl.AllGather(my_slab, C.gathered[(size_t)g] + (size_t)c * (size_t)G * slab_elems,
-                                                        slab_elems, GKM_NCCL_FLOAT64, g_rccl.comms[(size_t)g], sc);
-                if (r != 0 && !fail) { fail = true; C.err[(size_t)g] = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); }
+                MCHK(hipStreamWaitEvent(sc, R.ready[(size_t)c], 0));
+                MCHK(hipEventRecord(R.a0[(size_t)c], sc));
+                if (!fail) {
+                    const ncclResult_t r = g_rccl.AllGather(my_slab, R.gathered + (size_t)c * (size_t)G * slab_elems,
+                                                            slab_elems, GKM_NCCL_FLOAT64, g_rccl.comms[(size_t)g], sc);
+                    if (r != 0) { fail = true; C.err[(size_t)g] = std::string("ncclAllGather: ") + g_rccl.GetErrorString(r); }
+                }
+                MCHK(hipEventRecord(R.a1[(size_t)c], sc));
                 if (fail) C.failed = 1;
+                /* ... and agree again that EVERY rank has enqueued it: if one could not, the others' collective will
+                 * never complete, and nobody may wait for stream sc */
+                if (C.bar->wait(fail)) C.stuck = 1;
             }
         } else {
             /* every rank has RECORDED ready[.][c]: an unrecorded event would not be waited for */
             if (!C.bar->wait(C.failed.load() != 0)) {
+                MCHK(hipEventRecord(R.a0[(size_t)c], sc));
                 for (int r = 0; r < G && !fail; r++) {
-                    MCHK(hipStreamWaitEvent(sc, C.ready[(size_t)r][(size_t)c], 0));
-                    MCHK(hipMemcpyPeerAsync(C.gathered[(size_t)g] + ((size_t)c * (size_t)G + (size_t)r) * slab_elems, dev,
-                                            C.slab[(size_t)r] + (size_t)c * slab_elems, C.devs[(size_t)r],
+                    MCHK(hipStreamWaitEvent(sc, g_cache[r].ready[(size_t)c], 0));
+                    MCHK(hipMemcpyPeerAsync(R.gathered + ((size_t)c * (size_t)G + (size_t)r) * slab_elems, dev,
+                                            g_cache[r].slab + (size_t)c * slab_elems, C.devs[(size_t)r],
                                             slab_elems * sizeof(double), sc));
                 }
+                MCHK(hipEventRecord(R.a1[(size_t)c], sc));
                 if (fail) C.failed = 1;
             }
         }
@@ -230,28 +305,31 @@ void rank_thread(Call &C, int g)
     (void)gkmhip_set_scratch_slot(C.ctxs[g], 0);
 
     /* ---- phase 2: un-permute + normalise this device's copy of the whole matrix ---- */
+    bool assembled = false;
     if (!C.failed.load()) {
-        const int rc = gkmhip_assemble_normalize(C.ctxs[g], C.gathered[(size_t)g], n, d_slot, C.K[g], C.ld, sq, C.symmetric, sc);
+        MCHK(hipEventRecord(R.n0, sc));
+        const int rc = gkmhip_assemble_normalize(C.ctxs[g], R.gathered, n, R.d_slot, C.K[g], C.ld, R.sq, C.symmetric, sc);
         if (rc && !fail) { fail = true; C.err[(size_t)g] = gkmhip_last_error(); }
+        MCHK(hipEventRecord(R.n1, sc));
+        assembled = !fail;
     }
     for (int i = 0; i < 2; i++)
         if (sk[i]) (void)hipStreamSynchronize(sk[i]);
-    if (sc) {
+    if (sc && !C.stuck.load()) {
         hipError_t e = hipStreamSynchronize(sc);
         if (e != hipSuccess && !fail) { fail = true; C.err[(size_t)g] = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); }
     }
+    if (assembled && !fail) {
+        float ms = 0.f;
+        for (int c = 0; c < chunks; c++) {
+            if (hipEventElapsedTime(&ms, R.k0[(size_t)c], R.k1[(size_t)c]) == hipSuccess) st_out.kernel_ms += ms;
+            if (hipEventElapsedTime(&ms, R.a0[(size_t)c], R.a1[(size_t)c]) == hipSuccess) st_out.transfer_ms += ms;
+        }
+        if (hipEventElapsedTime(&ms, R.n0, R.n1) == hipSuccess) st_out.assemble_ms = ms;
+        g_stats[(size_t)g] = st_out;
+    }
     if (fail) C.failed = 1;
     C.bar->wait(); /* nobody reads this rank's slab any more */
-
-    if (d_slot) (void)hipFree(d_slot);
-    if (sq) (void)hipFree(sq);
-    if (C.slab[(size_t)g]) (void)hipFree(C.slab[(size_t)g]);
-    if (C.gathered[(size_t)g]) (void)hipFree(C.gathered[(size_t)g]);
-    for (int c = 0; c < chunks; c++)
-        if (C.ready[(size_t)g][(size_t)c]) (void)hipEventDestroy(C.ready[(size_t)g][(size_t)c]);
-    for (int i = 0; i < 2; i++)
-        if (sk[i]) (void)hipStreamDestroy(sk[i]);
-    if (sc) (void)hipStreamDestroy(sc);
 }
 
 } /* namespace */
@@ -261,7 +339,32 @@ extern "C" const char *gkmhip_last_transport(void) { return g_transport.c_str();
 extern "C" void gkmhip_release_comms(void)
 {
     std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
     if (g_rccl.AllGather) rccl_drop_comms();
+    for (RankCache &R : g_cache) cache_release(R);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+}
+
+extern "C" long gkmhip_allgather_alloc_count(void) { return g_allocs.load(); }
+
+/* out[0] = ranks, out[1] = chunks, out[2] = transport (0 none, 1 p2p, 2 rccl), then per rank
+ * {kernel ms (sum over chunks), transfer ms (sum over chunks), assemble ms, l-mer comparisons} */
+extern "C" int gkmhip_allgather_stats(double *out, int cap)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    const int need = 3 + 4 * (int)g_stats.size();
+    if (!out || cap < need || g_stats.empty()) return 0;
+    out[0] = (double)g_stats.size();
+    out[1] = (double)g_stats_chunks;
+    out[2] = g_transport == "rccl" ? 2.0 : g_transport == "p2p" ? 1.0 : 0.0;
+    for (size_t g = 0; g < g_stats.size(); g++) {
+        out[3 + 4 * g] = g_stats[g].kernel_ms;
+        out[4 + 4 * g] = g_stats[g].transfer_ms;
+        out[5 + 4 * g] = g_stats[g].assemble_ms;
+        out[6 + 4 * g] = g_stats[g].comparisons;
+    }
+    return need;
 }
 
 extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, int64_t ld, int symmetric, int chunks)
@@ -300,9 +403,8 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
     }
     g_transport = C.use_rccl ? "rccl" : (nctx > 1 ? "p2p" : "none");
 
-    C.slab.assign((size_t)nctx, nullptr);
-    C.gathered.assign((size_t)nctx, nullptr);
-    C.ready.assign((size_t)nctx, std::vector<hipEvent_t>((size_t)C.chunks, nullptr));
+    g_stats.assign((size_t)nctx, RankStats());
+    g_stats_chunks = C.chunks;
     C.err.assign((size_t)nctx, std::string());
     HostBarrier bar(nctx);
     C.bar = &bar;
@@ -312,8 +414,15 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
     for (int g = 1; g < nctx; g++) th.emplace_back(rank_thread, std::ref(C), g);
     rank_thread(C, 0);
     for (auto &t : th) t.join();
+    if (C.stuck.load()) {
+        /* a collective that some rank never joined: abort the communicators (which ends the waiting kernels) and
+         * drop the buffers they were writing; the next call starts from scratch */
+        rccl_drop_comms(true);
+        for (int g = 0; g < nctx; g++) cache_release(g_cache[g]);
+    }
     if (caller_device >= 0) (void)hipSetDevice(caller_device);
     if (C.failed.load()) {
+        g_stats.clear();
         std::string msg = "gkmhip_gram_allgather failed";
         for (int g = 0; g < nctx; g++)
             if (!C.err[(size_t)g].empty()) msg += "; rank " + std::to_string(g) + ": " + C.err[(size_t)g];

@@ -33,22 +33,52 @@ typedef struct {
     int nthreads;
     int rc;
     char err[256];
+    gkmhip_ctx *ctx;
+    double *dG;
 } device_job;
 
-static void *device_worker(void *arg)
+/* Two phases, with ALL devices through the first before any starts the second, so that what can reasonably fail --
+ * a device that cannot be used, the upload, the n x n allocation -- fails before a single cell of the caller's
+ * matrix has been written (the reference returns from its own checks before writing anything,
+ * src/gkmkern_pylib.c:157-161).  GKM_FAULT_INJECT=alloc:<part> makes that part's allocation fail (tests). */
+static void *device_setup(void *arg)
 {
     device_job *j = (device_job *)arg;
-    gkmhip_ctx *ctx = gkmhip_create(j->device, j->L, j->d, j->c, j->rbf, j->gamma);
-    double *dG = NULL;
+    const char *inject = getenv("GKM_FAULT_INJECT");
     j->rc = 1;
-    if (ctx && !gkmhip_set_sequences(ctx, j->n, j->codes, j->offsets, j->wd, j->wd_len, NULL) &&
-        (dG = (double *)gkmhip_malloc(j->device, (size_t)j->n * (size_t)j->n * sizeof(double))) != NULL &&
-        !gkmhip_gram_part_to_host_rows(ctx, dG, j->n, j->kmat, j->nthreads, j->part, j->nparts))
-        j->rc = 0;
+    j->ctx = gkmhip_create(j->device, j->L, j->d, j->c, j->rbf, j->gamma);
+    if (j->ctx && !gkmhip_set_sequences(j->ctx, j->n, j->codes, j->offsets, j->wd, j->wd_len, NULL)) {
+        if (inject && !strncmp(inject, "alloc:", 6) && atoi(inject + 6) == j->part) {
+            snprintf(j->err, sizeof j->err, "injected allocation failure (GKM_FAULT_INJECT)");
+            return NULL;
+        }
+        j->dG = (double *)gkmhip_malloc(j->device, (size_t)j->n * (size_t)j->n * sizeof(double));
+        if (j->dG) j->rc = 0;
+    }
     if (j->rc) snprintf(j->err, sizeof j->err, "%s", gkmhip_last_error());
-    if (dG) gkmhip_free(dG);
-    if (ctx) gkmhip_destroy(ctx);
     return NULL;
+}
+
+static void *device_compute(void *arg)
+{
+    device_job *j = (device_job *)arg;
+    j->rc = gkmhip_gram_part_to_host_rows(j->ctx, j->dG, j->n, j->kmat, j->nthreads, j->part, j->nparts) ? 1 : 0;
+    if (j->rc) snprintf(j->err, sizeof j->err, "%s", gkmhip_last_error());
+    return NULL;
+}
+
+/* `phase` for every job: job 0 on the calling thread, the others on threads of their own (or here, one after the
+ * other, if a thread cannot be started) */
+static void run_on_all_devices(device_job *jobs, int ndev, void *(*phase)(void *))
+{
+    pthread_t th[GKM_MAX_DEVICES];
+    int started[GKM_MAX_DEVICES];
+    for (int i = 1; i < ndev; i++) started[i] = pthread_create(&th[i], NULL, phase, &jobs[i]) == 0;
+    phase(&jobs[0]);
+    for (int i = 1; i < ndev; i++) {
+        if (started[i]) pthread_join(th[i], NULL);
+        else phase(&jobs[i]);
+    }
 }
 
 static double now_ms(void)
@@ -228,25 +258,32 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
         }
     } else {
         device_job jobs[GKM_MAX_DEVICES];
-        pthread_t th[GKM_MAX_DEVICES];
-        int started[GKM_MAX_DEVICES];
+        int failed = 0;
         for (int i = 0; i < ndev; i++) {
             device_job j = {devs[i], i, ndev, L, d, c, rbf, opts->gamma, n, gkm_problem_all_codes(prob),
-                            gkm_problem_offsets(prob), wd, wd_len, kmat, opts->nthreads > 0 ? opts->nthreads : 1, 0, {0}};
+                            gkm_problem_offsets(prob), wd, wd_len, kmat, opts->nthreads > 0 ? opts->nthreads : 1, 0, {0},
+                            NULL, NULL};
             jobs[i] = j;
-            started[i] = (i > 0 && pthread_create(&th[i], NULL, device_worker, &jobs[i]) == 0);
         }
-        device_worker(&jobs[0]);
-        for (int i = 1; i < ndev; i++) {
-            if (started[i]) pthread_join(th[i], NULL);
-            else device_worker(&jobs[i]); /* could not start a thread: do that share here */
-        }
-        int failed = 0;
+        run_on_all_devices(jobs, ndev, device_setup);
         for (int i = 0; i < ndev; i++)
             if (jobs[i].rc) {
                 gkm_log(GKM_LOG_ERROR, "HIP device %d: %s", jobs[i].device, jobs[i].err);
                 failed = 1;
             }
+        /* nothing has been written to the caller's rows yet: a device that failed here leaves them untouched */
+        if (!failed) {
+            run_on_all_devices(jobs, ndev, device_compute);
+            for (int i = 0; i < ndev; i++)
+                if (jobs[i].rc) {
+                    gkm_log(GKM_LOG_ERROR, "HIP device %d: %s", jobs[i].device, jobs[i].err);
+                    failed = 1;
+                }
+        }
+        for (int i = 0; i < ndev; i++) {
+            if (jobs[i].dG) gkmhip_free(jobs[i].dG);
+            if (jobs[i].ctx) gkmhip_destroy(jobs[i].ctx);
+        }
         if (failed) goto done;
         gkm_log(GKM_LOG_DEBUG, "row blocks computed on %d devices", ndev);
     }

@@ -137,6 +137,10 @@ def load():
     L.gkmhip_gram_allgather.argtypes = (vp, i32, vp, i64, i32, i32)
     L.gkmhip_last_transport.restype = ctypes.c_char_p
     L.gkmhip_release_comms.restype = None
+    if hasattr(L, "gkmhip_allgather_stats"):   # (older builds loaded through GKM_LIB_PATH for A/B timing lack them)
+        L.gkmhip_allgather_alloc_count.restype = ctypes.c_long
+        L.gkmhip_allgather_stats.restype = i32
+        L.gkmhip_allgather_stats.argtypes = (vp, i32)
     L.gkmhip_assemble_normalize.restype = i32
     L.gkmhip_assemble_normalize.argtypes = (vp, vp, i64, vp, vp, i64, vp, i32, vp)
     L.gkmhip_last_kernel_ms.restype = dbl
@@ -369,10 +373,11 @@ def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, slot
     return ctx
 
 
-def release_cached_contexts():
-    for ctx in _CTX_CACHE.values():
-        ctx.close()
-    _CTX_CACHE.clear()
+def release_cached_contexts(device=None, slot=None):
+    """Close the cached contexts (all of them, or those of one device / slot): each keeps its device scratch --
+    the tile-transposed output alone is ~0.6 GB at n = 10 000 -- for as long as it lives."""
+    for key in [k for k in _CTX_CACHE if (device is None or k[0] == device) and (slot is None or k[1] == slot)]:
+        _CTX_CACHE.pop(key).close()
 
 
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,
@@ -403,6 +408,19 @@ def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, w
     finally:
         if not keep_context:
             ctx.close()
+
+
+def allgather_stats():
+    """Per-rank HIP-event timings of the most recent gkmhip_gram_allgather (include/gkm_hip.h)."""
+    buf = np.zeros(3 + 4 * 64)
+    got = load().gkmhip_allgather_stats(buf.ctypes.data, len(buf))
+    if not got:
+        return None
+    G = int(buf[0])
+    per = buf[3:3 + 4 * G].reshape(G, 4)
+    return dict(ranks=G, chunks=int(buf[1]), transport=("none", "p2p", "rccl")[int(buf[2])],
+                kernel_ms=per[:, 0].tolist(), transfer_ms=per[:, 1].tolist(), assemble_ms=per[:, 2].tolist(),
+                comparisons=per[:, 3].tolist())
 
 
 def gram_matrix_multi(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devices=(0,), symmetric=False, chunks=0,

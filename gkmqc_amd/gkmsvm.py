@@ -198,6 +198,9 @@ def _init_many_on(pairs, args, gpu, slot):
     finally:
         handoff.put(None)
         th.join()
+        # the worker's context was kept from subset to subset; the run is over (the solver too: nothing left on the
+        # device that its hipFree could wait for), so its scratch goes back before the caller allocates anything else
+        device.release_cached_contexts(gpu, slot)
     if errors:
         raise errors[0]
     return results

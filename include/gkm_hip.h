@@ -145,8 +145,19 @@ int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
 int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, int64_t ld, int symmetric, int chunks);
 /* "rccl", "p2p" or "none": how the most recent gkmhip_gram_allgather moved the slabs */
 const char *gkmhip_last_transport(void);
-/* RCCL communicators are kept for the life of the process; this destroys them (optional) */
+/* RCCL communicators AND each rank's buffers (its slab, the gathered slabs, gather index, self norms, streams,
+ * events: ~1.7 GB per device at n = 10 000 on two devices) are kept for the life of the process, keyed by
+ * (device, n, ranks, chunks): bin/gkmqc.py asks for ~20 matrices of one size per run, and hipMalloc / hipFree
+ * synchronise the device.  This destroys the communicators and frees the buffers (optional). */
 void gkmhip_release_comms(void);
+/* hipMalloc calls gkmhip_gram_allgather has made so far in this process (a second call of the same shape makes
+ * none) */
+long gkmhip_allgather_alloc_count(void);
+/* What the most recent successful gkmhip_gram_allgather measured with HIP events on its own streams:
+ * out[0] = ranks, out[1] = chunks, out[2] = transport (0 none, 1 peer copies, 2 RCCL), then for every rank
+ * {kernel ms summed over its chunks, transfer ms summed over its chunks, un-permute + normalise ms, l-mer
+ * comparisons of its rows}.  Returns the number of doubles written, 0 if `cap` is too small or nothing ran. */
+int gkmhip_allgather_stats(double *out, int cap);
 
 /* Un-permutation + normalisation in one pass: matrix row a is row slot_of_row[a] (device array, n
  * int64) of `slabs` (device, leading dimension lds, raw values); K receives what gkmhip_normalize

@@ -23,6 +23,15 @@
  *               library never calls exit(): unreadable files, bad verbosity, empty
  *               FASTA, sequences shorter than L, missing GPU and HIP errors all
  *               return non-zero after an ERROR log line.
+ *   on failure  Everything that is checked or set up before the computation -- the
+ *               parameters, both files, the device list (GKM_DEVICE / GKM_DEVICES),
+ *               every device's context, upload and n x n allocation, on ALL devices
+ *               when several are used -- fails BEFORE a single cell of kmat or
+ *               kmat_size has been written (the reference returns from its own
+ *               checks before writing anything, gkmkern_pylib.c:157-161).  Only a HIP
+ *               error during the computation itself (a failed launch or copy) can
+ *               leave rows partly written; the return value is non-zero then too and
+ *               the caller must discard the matrix (scripts/gkmsvm.py:90-92 does).
  */
 #ifndef GKMKERN_PYLIB_H
 #define GKMKERN_PYLIB_H

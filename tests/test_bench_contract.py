@@ -60,8 +60,17 @@ def test_plain_gpus_2_launches_its_own_ranks(built, assembly):
     line with n_gpus 2, and --check holds the assembled matrix to the single-GPU one bit for bit."""
     env = {"GKM_BENCH_SHARE_GPU": "1", "GKM_BENCH_BACKEND": "gloo"}
     d = _one_line(_run(["--gpus", "2", "--assembly", assembly, "--check", "--no-cpu-baseline"] + SMALL, env))
-    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] is None
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] is None   # custom size: no PMC summary applies
     assert "end_to_end" not in d and "cpu_baseline" not in d
+    # what an N > 1 line says about itself: ranks, transport, every rank's own kernel, the collective, the assembly
+    rf, cfg = d["roofline"], d["config"]
+    assert cfg["ranks"] == 2 and cfg["chunks"] >= 1
+    assert cfg["transport"] == ("gloo" if assembly == "torch" else "p2p")
+    assert len(rf["kernel_ms_per_rank"]) == 2 and min(rf["kernel_ms_per_rank"]) > 0
+    assert rf["kernel_ms_min"] <= rf["kernel_ms_max"] and rf["allgather_ms"] > 0 and rf["assemble_ms"] > 0
+    assert sum(rf["comparisons_per_rank"]) == pytest.approx(2.0 * 290 * 290 * (800 * 801 / 2), rel=1e-9)
+    if assembly == "cabi":   # the buffers of gkmhip_gram_allgather are kept between calls (warm-up call included)
+        assert rf["allgather_hipmalloc_calls_in_timed_region"] == 0
 
 
 def test_headline_roofline_uses_only_a_matching_pmc_summary(tmp_path, monkeypatch):
@@ -83,6 +92,52 @@ def test_headline_roofline_uses_only_a_matching_pmc_summary(tmp_path, monkeypatc
     (tmp_path / bench.KERNEL_SOURCES[0]).write_text("v2: the kernel changed")
     d, why = bench.pmc_summary("c2")
     assert d is None and "stale" in why
+
+
+def test_multi_gpu_roofline_fields():
+    """N > 1: frac = the one-GPU launch's executed lane-ops / (max-over-ranks step time x N x peak), and each
+    rank's own kernel against one GPU's peak."""
+    sys.path.insert(0, ROOT)
+    import bench
+    per_rank = [{"kernel_ms": 40.0, "comparisons": 4.0e12, "allgather_ms": 3.0, "assemble_ms": 0.5},
+                {"kernel_ms": 50.0, "comparisons": 4.4e12, "allgather_ms": 3.5, "assemble_ms": 0.4}]
+    insts = 7.0e10
+    m = bench.multi_gpu_roofline(insts, per_rank, 0.060, 2)
+    assert m["frac"] == pytest.approx(insts * 64 / 0.060 / 1e9 / (2 * bench.PEAK_INT32_GOPS))
+    ipc = insts * 64 / 8.4e12
+    assert m["executed_insts_per_comparison"] == pytest.approx(ipc)
+    assert m["frac_per_rank_kernel"][1] == pytest.approx(ipc * 4.4e12 / 0.050 / 1e9 / bench.PEAK_INT32_GOPS)
+    assert (m["kernel_ms_min"], m["kernel_ms_max"], m["allgather_ms"], m["assemble_ms"]) == (40.0, 50.0, 3.5, 0.5)
+    none = bench.multi_gpu_roofline(None, per_rank, 0.060, 2)       # no matching PMC summary: nulls, never guesses
+    assert none["frac"] is None and none["frac_per_rank_kernel"] == [None, None] and none["kernel_ms_max"] == 50.0
+
+
+def test_launcher_stops_the_other_ranks_when_one_fails():
+    """A rank that dies before the process group forms must not leave its peers (and the parent) waiting: the
+    parent polls every child, ends the rest on the first non-zero exit and reports failure within seconds; the
+    same for the overall timeout.  Rank 0's stdout is relayed only on success."""
+    import time
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    args = types.SimpleNamespace(gpus=3)
+    prog = ("import os, sys, time\nr = int(os.environ['RANK'])\nassert os.environ['WORLD_SIZE'] == '3'\n"
+            "if r == 1:\n    time.sleep(0.3); sys.exit(3)\nprint('{}', flush=True)\ntime.sleep(120)\n")
+    t0 = time.time()
+    assert bench.launch_ranks(args, [], cmd=[sys.executable, "-c", prog]) != 0
+    assert time.time() - t0 < 20
+    t0 = time.time()
+    assert bench.launch_ranks(args, [], cmd=[sys.executable, "-c", "import time; time.sleep(120)"], timeout=1.0) != 0
+    assert time.time() - t0 < 20
+    assert bench.launch_ranks(args, [], cmd=[sys.executable, "-c", "print('{}')"]) == 0
+
+
+def test_default_cpu_baseline_is_the_headline_workload():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.parse_args([]).cpu_sample == 5000                      # the whole of config 2 (~90 s on 16 cores)
+    assert bench.parse_args(["--workload", "peaks"]).cpu_sample == 2000  # bounded elsewhere
+    assert bench.parse_args(["--cpu-sample", "300"]).cpu_sample == 300
 
 
 def test_workload_table_matches_baseline_configs():

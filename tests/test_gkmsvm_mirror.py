@@ -124,6 +124,36 @@ def test_config4_stand_in_at_full_size(built, tmp_path, gpus):
 
 
 @pytest.mark.gpu
+def test_config4_as_the_pipeline_runs_it(built, tmp_path):
+    """BASELINE configs[3] the way `gkmqc.py evaluate` drives it (reference bin/gkmqc.py:150-154,213-216,338-343): one
+    subset after the other, each 5 000 peaks of 600 bp + 5 000 matched nulls, wgkm L=10 k=6 d=3, 5-fold x 10 repeats
+    (`-x 5 -r 10`).  Three full-size subsets through init_many (cross-validation of one subset beside the matrix of the
+    next, the device context kept from subset to subset): the same AUCs and the same three eval lines as one init per
+    subset, and for the subset the fixture was made from, the AUC the reference's own module returned at 10 repeats
+    (tests/golden/make_golden_gkmsvm.py --c4)."""
+    from gkmqc_amd import gkmsvm, synth
+    case = json.load(open(os.path.join(helpers.GOLDEN, "gkmsvm_expected_c4.json")))["c4_peaks_r10"]
+    pairs = []
+    for s, (sp, sn) in enumerate(((11, 12), (21, 22), (31, 32))):      # (11, 12): the fixture's subset
+        pf, nf = str(tmp_path / ("p%d.fa" % s)), str(tmp_path / ("n%d.fa" % s))
+        synth.write_peak_problem(pf, nf, 5000, 5000, 600, seed_pos=sp, seed_neg=sn)
+        pairs.append((pf, nf))
+    C, eps, shrinking, cache, ncv, repeats, _fast, seed, _procs = case["args_svm"]
+    assert (ncv, repeats) == (5, 10)
+    base = ["-s", str(seed), "-v", "0", "-t", "4", "-L", "10", "-k", "6", "-d", "3", "-x", str(ncv), "-r", str(repeats),
+            "-C", str(C), "-e", str(eps), "-u", str(shrinking), "-c", str(cache)]
+    a1 = gkmsvm.build_parser().parse_args(["-p", "x", "-n", "y", "-w", str(tmp_path / "seq")] + base)
+    a2 = gkmsvm.build_parser().parse_args(["-p", "x", "-n", "y", "-w", str(tmp_path / "many")] + base)
+    want = [gkmsvm.init(p, n, a1) for p, n in pairs]
+    got = gkmsvm.init_many(pairs, a2)
+    assert got == want
+    assert abs(got[0][0] - case["auc_mean"]) < 1e-12 and abs(got[0][1] - case["auc_std"]) < 1e-12
+    lines = open(str(tmp_path / "many") + ".gkmqc.eval.out").read().splitlines()
+    assert len(lines) == 3 and lines == open(str(tmp_path / "seq") + ".gkmqc.eval.out").read().splitlines()
+    assert len({ln.split("\t")[3] for ln in lines}) == 3               # three different subsets, three different AUCs
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n,rng", [(4400, None), (2000, (150, 600))])
 def test_boundary_blocks_and_pieces_against_one_launch(built, tmp_path, monkeypatch, n, rng):
     """The drop-in call cuts the matrix into geometrically shrinking row blocks (one Gram launch each) that travel

@@ -307,6 +307,25 @@ def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
         assert (res["K"].cpu().numpy() == want["K"].cpu().numpy()).all()
 
 
+def test_reused_context_with_longer_second_subset(dev):
+    """A cached context (gkmsvm.init_many keeps one per device) evaluated on a second subset whose sequences are
+    longer: every per-sequence table (strand bit planes, packed strands, the dynamic LDS they size) must follow
+    the NEW subset.  Short -> long -> short again, weighted and unweighted, bit for bit against fresh contexts."""
+    first = helpers.synth_codes(70, 70, 300, (150, 280))
+    second = helpers.synth_codes(60, 60, 600, (590, 700))     # maxlen larger by far more than 16 bp
+    try:
+        for t, L, k, d in ((4, 10, 6, 3), (2, 11, 7, 3)):
+            for seqs in (first, second, first):
+                kept = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE, keep_context=True,
+                                       context_slot=7)
+                fresh = dev.gram_matrix(seqs, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+                il = np.tril_indices(len(seqs))
+                assert (kept["P"].cpu().numpy()[il] == fresh["P"].cpu().numpy()[il]).all()
+                assert (kept["K"].cpu().numpy() == fresh["K"].cpu().numpy()).all()
+    finally:
+        dev.release_cached_contexts()
+
+
 def test_many_short_rows_take_the_128_slot_variant(dev):
     """Rows much shorter than a lane: more than 64 of them fit a tile, so the host keeps 128 row slots
     (capping the tile at 64 rows would leave lanes empty); ragged 150-600 bp rows take the 64-slot variant."""
@@ -400,6 +419,35 @@ def test_boundary_over_several_device_contexts(dev, monkeypatch, devices):
     assert helpers.max_rel_err(helpers.tril_pack(many), z["c2_cut192_K"]) < K_TOL
 
 
+@pytest.mark.parametrize("part", [0, 1, 2])
+def test_multi_device_boundary_failure_leaves_the_matrix_untouched(dev, monkeypatch, tmp_path, part):
+    """GKM_DEVICES path: every device goes through context, upload and allocation BEFORE any device computes, so a
+    device that fails there (here: an injected allocation failure on one of three) makes the call return non-zero
+    without a single cell of the caller's matrix or of kmat_size written -- the reference returns from its own checks
+    before writing anything (src/gkmkern_pylib.c:157-161).  The next call, without the fault, works."""
+    from gkmqc_amd import synth
+    pf, nf = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+    synth.write_problem(pf, nf, 150, 150, 300)
+    n = 300
+    kmat = np.full((n, n), -7.5)
+    rows = (kmat.ctypes.data + np.arange(n) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.full(2, -3, dtype=np.int32)
+    opt = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, pf.encode(), nf.encode(), 2, 0)
+    monkeypatch.setenv("GKM_DEVICES", "0,0,0")
+    monkeypatch.setenv("GKM_FAULT_INJECT", "alloc:%d" % part)
+    assert dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data) != 0
+    assert (kmat == -7.5).all() and (sizes == -3).all()
+    monkeypatch.delenv("GKM_FAULT_INJECT")
+    assert dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data) == 0
+    assert (np.diag(kmat) == 1.0).all() and (kmat[np.triu_indices(n, 1)] == -7.5).all() and tuple(sizes) == (150, 150)
+    monkeypatch.delenv("GKM_DEVICES")
+    one = np.zeros((n, n))
+    rows1 = (one.ctypes.data + np.arange(n) * one.strides[0]).astype(np.uintp)
+    assert dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows1.ctypes.data, sizes.ctypes.data) == 0
+    il = np.tril_indices(n)
+    assert (kmat[il] == one[il]).all()
+
+
 @pytest.mark.parametrize("nctx,chunks", [(2, 0), (3, 2), (5, 4)])
 def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
     """gkmhip_gram_allgather (include/gkm_hip.h): several contexts -- here all on the one GPU of the
@@ -417,6 +465,40 @@ def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
             assert torch.equal(K, one), "assembled matrix differs from the single-GPU matrix"
         low = dev.gram_matrix_multi(problem, t, L, k, d, gamma=2.0, devices=[0] * nctx, symmetric=False, chunks=chunks)
         assert torch.equal(low["K"][nctx - 1], torch.tril(one))
+
+
+def test_one_process_assembly_keeps_its_buffers(dev):
+    """gkmhip_gram_allgather keeps each rank's slab, gathered slabs, gather index, streams and events between calls of
+    the same shape (bin/gkmqc.py asks for ~20 matrices of one size per run; hipMalloc / hipFree synchronise the
+    device): the second call makes no hipMalloc, a call of another shape rebuilds them, and the per-rank HIP-event
+    statistics of a call are there to read."""
+    import torch
+    lib = dev.load()
+    a = helpers.synth_codes(200, 200, 300)
+    b = helpers.synth_codes(120, 130, 300, (150, 400))
+    one_a = dev.gram_matrix(a, 4, 11, 7, 3)["K"]
+    one_b = dev.gram_matrix(b, 4, 11, 7, 3)["K"]
+    lib.gkmhip_release_comms()
+    n0 = lib.gkmhip_allgather_alloc_count()
+    first = dev.gram_matrix_multi(a, 4, 11, 7, 3, devices=[0, 0], chunks=3)
+    n1 = lib.gkmhip_allgather_alloc_count()
+    assert n1 > n0 and torch.equal(first["K"][1], one_a)
+    again = dev.gram_matrix_multi(a, 4, 11, 7, 3, devices=[0, 0], chunks=3)      # fresh contexts, same shape
+    assert lib.gkmhip_allgather_alloc_count() == n1, "the second call of the same shape allocated device memory"
+    assert torch.equal(again["K"][0], one_a) and torch.equal(again["K"][1], one_a)
+    st = dev.allgather_stats()
+    assert st["ranks"] == 2 and st["chunks"] == 3 and st["transport"] == "p2p"
+    assert min(st["kernel_ms"]) > 0 and min(st["transfer_ms"]) > 0 and min(st["assemble_ms"]) > 0
+    n = len(a)
+    assert sum(st["comparisons"]) == 2.0 * 290 * 290 * (n * (n + 1) / 2)        # every (a, j <= a) pair exactly once
+    other = dev.gram_matrix_multi(b, 4, 11, 7, 3, devices=[0, 0], chunks=3)      # another n: rebuilt, still right
+    assert lib.gkmhip_allgather_alloc_count() > n1 and torch.equal(other["K"][1], one_b)
+    back = dev.gram_matrix_multi(a, 4, 11, 7, 3, devices=[0, 0, 0], chunks=2)    # another rank count
+    assert all(torch.equal(K, one_a) for K in back["K"])
+    lib.gkmhip_release_comms()
+    after = dev.gram_matrix_multi(a, 4, 11, 7, 3, devices=[0, 0], chunks=3)      # released: allocates again, still right
+    assert torch.equal(after["K"][0], one_a)
+    lib.gkmhip_release_comms()
 
 
 def test_one_process_assembly_through_rccl(dev, monkeypatch):
