@@ -107,6 +107,31 @@ def pmc_summary(workload):
     return None, "no PMC summary for workload %s under profiles/" % workload
 
 
+def issue_model(workload):
+    """tools/issue_model.py's summary for this workload and THIS kernel source (profiles/r*_issue_model.json): the hot
+    kernel's VALU instructions priced with gfx950's per-opcode issue rates against the SIMD-cycles its launch had."""
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_issue_model.json")), reverse=True):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        w = d.get("workloads", {}).get(workload)
+        if d.get("kernel_source_sha256") == want and w:
+            m = w["measured"]
+            return {"source": os.path.basename(path), "issue_cycles_over_simd_cycles": m["issue_frac"],
+                    "valu_instructions_in_trips": m["valu_in_trips"], "issue_cycles_in_trips": m["issue_cycles_in_trips"],
+                    "cycles_full_rate": d["cycles_full_rate"], "cycles_sgpr_operand": d["cycles_sgpr_operand"],
+                    "cycles_half_rate": d["cycles_half_rate"],
+                    "per_shift": {k: w["per_shift"][k] for k in ("full_rate", "sgpr_operand", "half_rate", "cycles")},
+                    "per_trip": {k: w["trip"][k] for k in ("full_rate", "sgpr_operand", "half_rate", "cycles")},
+                    "note": "frac above prices every VALU instruction alike (peak = one per 2 cycles and SIMD); on gfx950 only "
+                            "v_and/or/xor/add/sub/not/mov/lshrrev/ashrrev/bitop3 on VGPRs issue that fast, everything else and "
+                            "any SGPR operand take about twice as long (profiles/r3_valu_ops.txt). Priced per opcode, the "
+                            "kernel's VALU issue fills this fraction of the SIMD-cycles of its launch."}
+    return None
+
+
 def measured_valu_peak():
     """Lane-ops/s a pure full-rate VALU stream sustains on the box (tools/valu_peak.hip), Gop/s."""
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_peak.json")), reverse=True):
@@ -274,7 +299,8 @@ def side_workload(name, dev, steps=3):
         return {"workload": a.label, "n_sequences": n, "length": a.length_range or a.length, "L": a.L, "k": a.k, "d": a.d,
                 "steps": steps, "ms_per_step": wall * 1e3, "pairs_per_s": (n * (n - 1) / 2) / wall,
                 "kernel": ctx.last_kernel_name(), "kernel_ms": kern_s * 1e3, "comparisons_per_s": comparisons / kern_s,
-                "frac": (insts * 64 / kern_s / 1e9 / PEAK_INT32_GOPS) if insts else None, "pmc_source": src}
+                "frac": (insts * 64 / kern_s / 1e9 / PEAK_INT32_GOPS) if insts else None, "pmc_source": src,
+                "issue_cycles_over_simd_cycles": (issue_model(name) or {}).get("issue_cycles_over_simd_cycles")}
     finally:
         ctx.close()
 
@@ -696,6 +722,8 @@ def run_rank(args):
                     "(256 CU x 4 SIMD x 32 lanes x 2.4 GHz); null when the committed PMC summary was not taken on this "
                     "kernel source + workload. kernel_ms: HIP events on the launch stream. HBM traffic is incidental.",
         }
+        if n_gpus == 1 and not args.custom and args.kernel == "auto":
+            out["roofline"]["issue_model"] = issue_model(args.workload)
         if n_gpus > 1:
             rf = out["roofline"]
             rf.update(multi)
