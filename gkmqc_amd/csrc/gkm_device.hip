@@ -484,9 +484,8 @@ constexpr int BS_GRP = GKM_BS_GRP;     /* hit words per list record: the lanes a
 #endif
 constexpr int BS_TRIP = GKM_BS_TRIP; /* records resolved per trip: one per lane */
 static_assert(BS_TRIP == 64, "a trip resolves one record per lane");
-/* records the wave-wide hit list (a ring) holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
+/* records the wave-wide hit list holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
 constexpr int BS_CAP = BS_TRIP + 64;
-constexpr bool BS_CAP_POW2 = (BS_CAP & (BS_CAP - 1)) == 0;
 #ifndef GKM_BS_DU
 #define GKM_BS_DU 4 /* shifts per refill of the column words.  Round 2's final kernel, same-run A/B, config 2 / gkmQC's
                        defaults / config 5: 1 -> 78.2 / 437.2 / 177.9 ms, 2 -> 77.0-77.5 / 436.8-437.6 / 176.7, 3 -> 76.7 / 437.0 /
@@ -505,7 +504,7 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * One wavefront = 64 row segments (one per lane) x ONE column sequence.
  * For both strands of the column the wave sweeps all T cyclic shifts; per shift each lane
  * evaluates 32*W l-mer window comparisons with ~13 VALU instructions per 32 (gkm_bitslice.h).
- * Hit words are parked, compacted over the lanes, in a wave-wide LDS ring of records and turned
+ * Hit words are parked, compacted over the lanes, in a wave-wide LDS list (a stack) of records and turned
  * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
  * control flow besides the push.
  */
@@ -529,7 +528,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      * 434 vs 454 ms on gkmQC's defaults -- what an LDS-resident copy of the tile's 5.4 KB could gain at best, before paying for it;
      * 2048 = column words made up by scalar arithmetic instead of scalar loads (what hiding the scalar-load latency could gain) */
     using namespace gkmbs;
-    /* LDS per wave: 3 KB hit ring + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
+    /* LDS per wave: 3 KB hit list + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
      * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
      * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
      * of the row lane's packed positions from global memory (5.4 KB per tile, L1 resident: the waves of a CU
@@ -557,13 +556,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     __shared__ uint32_t lpiece[PACKED ? 64 * NP : BPERM ? 1 : 128];
     __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
-    /* The list is a ring: a trip is due as soon as it holds BS_TRIP records and it is checked after
-     * every group (at most 64 new records), a trip pops BS_TRIP records before it appends at most as
-     * many again: the ring never holds more than BS_TRIP + 63 records. */
+    /* The list is a STACK (round 3; a ring before): a trip is due as soon as it holds BS_TRIP records and it is checked
+     * after every group (at most 64 new records); a trip takes the BS_TRIP records on TOP and puts at most as many back:
+     * the list never holds more than BS_TRIP + 63 records.  The order in which hits are resolved is immaterial
+     * (integer adds), and a stack needs no head and no wrap: one AND less per push, per trip and per re-push, and the
+     * trip's read address is lane * 4 + a scalar. */
     static_assert(BS_CAP >= BS_TRIP + 64 && BS_CAP % 64 == 0, "hit list too small");
-    auto ring = [](uint32_t x) { /* x mod BS_CAP for x < 2 BS_CAP */
-        return BS_CAP_POW2 ? (x & (uint32_t)(BS_CAP - 1)) : min(x, x - (uint32_t)BS_CAP);
-    };
     static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
@@ -632,7 +630,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
-        int s_n = 0, s_hd = 0; /* records in the hit ring and its head (wave-uniform) */
+        int s_n = 0; /* records in the hit list (wave-uniform) */
 
         /* One hit -> accl[m][row slot] += wa * wb.  (meta + sel, bit) name the row lane r, the lane position
          * i0 = bit*W + w of the window, the shift and the strand; lane and bit row name the piece (gkm_pack.h),
@@ -688,11 +686,15 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             }
         };
 
-        /* one trip over the `c` records at the head of the ring (PARTIAL: c < BS_TRIP, the last trip of a column) */
+        /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
         auto trip = [&](auto partial_tag, int c) {
             constexpr bool PARTIAL = decltype(partial_tag)::value;
-            static_assert(BS_CAP_POW2, "ring offsets wrap with one AND");
-            const char *const at = (const char *)s_list + ((((uint32_t)s_hd << 2) + lane4) & (uint32_t)(BS_CAP * 4 - 1));
+            /* the c records on top: lane * 4 + a scalar (kept apart from the lane term: hipcc would fuse the shift into a
+             * half-rate v_lshl_add_u32 and split the reads around a negative offset) */
+            const uint32_t top4 = (uint32_t)__builtin_amdgcn_readfirstlane((s_n - c) << 2);
+            uint32_t at_off;
+            asm("v_add_u32 %0, %1, %2" : "=v"(at_off) : "s"(top4), "v"(lane4));
+            const char *const at = (const char *)s_list + at_off;
             uint32_t h[BS_GRP];
             /* (every ring slot is readable: the lanes past the end of a short, final trip are
              * cleared afterwards instead of being masked out of the loads) */
@@ -718,7 +720,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             }
             /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
             if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
-            s_hd = (int)ring((uint32_t)(s_hd + c));
             s_n -= c;
             const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
                                                            : __ballot(total > 1u);
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
                 if (total > 1u) {
-                    char *const to = (char *)s_list + (((rank << 2) + ((uint32_t)(s_hd + s_n) << 2)) & (uint32_t)(BS_CAP * 4 - 1));
+                    char *const to = (char *)s_list + ((rank + (uint32_t)s_n) << 2);
 #pragma unroll
                     for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
                     *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
@@ -738,11 +739,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         };
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
          * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
-         * again.  Fewer than one trip's worth of records waits in the ring; the last call of a column
+         * again.  Fewer than one trip's worth of records waits in the list; the last call of a column
          * (final) empties it.
          * No select chains: the position of the first hit is min over the words of ffbl(word) | 32 g
          * (v_ffbl_b32 gives all ones for an empty word, so empty words lose the min), the number of
-         * hits left is a popcount sum, and a record that goes back to the ring is copied unchanged and
+         * hits left is a popcount sum, and a record that goes back to the list is copied unchanged and
          * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
         auto trips = [&](bool final) {
             if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
@@ -802,9 +803,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                             const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             if (any != 0u) {
-                                char *const at = (char *)s_list + (BS_CAP_POW2
-                                    ? ((((uint32_t)rank + (uint32_t)(s_hd + s_n)) << 2) & (uint32_t)(BS_CAP * 4 - 1))
-                                    : (ring((uint32_t)rank + ring((uint32_t)(s_hd + s_n))) << 2));
+                                char *const at = (char *)s_list + (((uint32_t)rank + (uint32_t)s_n) << 2);
 #pragma unroll
                                 for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
                                 *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;

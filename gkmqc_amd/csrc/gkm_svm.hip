@@ -990,6 +990,9 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
         else if (maxl <= 1024 * 12) { T = 1024; R = 12; }
         else { T = 1024; R = 16; }
     }
+    /* (The 1024-thread shapes take 80-144 KB of dynamic LDS.  This library carries code objects for gfx950 only -- 160 KB of
+     * LDS per workgroup -- so there is no device that could load it and refuse that size; should the attribute call fail
+     * all the same, the error is reported, and gkmsvm_train_batch_general (no LDS-resident state) solves any fold.) */
 #define SMO_LAUNCH(TT, RR, TB)                                                                                  \
     if (T == TT && R == RR) {                                                                                   \
         const size_t dyn = TB == 1 ? (size_t)TT * RR * 12 : TB == 2 ? (size_t)TT * RR * 8 : 0;                  \

@@ -77,18 +77,17 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, 
 
 
 def _svm_fold(job):
+    """One fold on the host with scikit-learn's C-SVC on the precomputed kernel -- the solver, and the arguments, the
+    reference hands each fold to (scripts/gkmsvm.py:104-122); used for `--svm-solver sklearn` and as the fallback of the
+    GPU solver.  -> the fold's AUC."""
     from sklearn.metrics import roc_auc_score
     from sklearn.svm import SVC
-    args_svm, y, train, test = job
-    regularization, precision, shrinking, cache_size = args_svm[:4]
-    k_train = _KMAT[train, :][:, train]
-    k_test = _KMAT[test, :][:, train]
-    sv = SVC(kernel="precomputed", C=regularization, tol=precision, shrinking=bool(shrinking), gamma=1.0,
-             cache_size=cache_size)
-    score = sv.fit(k_train, y[train]).decision_function(k_test)
-    auc = roc_auc_score(y[test], score)
-    nu = np.sum(np.abs(sv.dual_coef_[0])) / len(train)
-    logging.info("SVC training and validation; nu = %.3f, AUC = %.3f", nu, auc)
+    (C, tol, shrinking, cache_mb), y, train, test = job[0][:4], job[1], job[2], job[3]
+    model = SVC(kernel="precomputed", C=C, tol=tol, shrinking=bool(shrinking), gamma=1.0, cache_size=cache_mb)
+    model.fit(_KMAT[np.ix_(train, train)], y[train])
+    auc = roc_auc_score(y[test], model.decision_function(_KMAT[np.ix_(test, train)]))
+    logging.info("fold of %d + %d samples on the host: nu %.3f, AUC %.3f", len(train), len(test),
+                 np.abs(model.dual_coef_[0]).sum() / len(train), auc)
     return auc
 
 

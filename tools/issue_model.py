@@ -105,7 +105,7 @@ def analyse(obj, kernel, du):
         j = i
         while j > 0 and not lines[j].startswith("ds_read2st64_b32"):
             j -= 1
-        while j > 0 and lines[j - 1].startswith(("ds_read2st64_b32", "v_and_b32", "v_add_lshl_u32")):
+        while j > 0 and lines[j - 1].startswith(("ds_read2st64_b32", "v_and_b32", "v_add_lshl_u32", "v_add_u32")):
             j -= 1
         starts.append([j, i])
     copies = []
