@@ -405,11 +405,13 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
 
     g_stats.assign((size_t)nctx, RankStats());
     g_stats_chunks = C.chunks;
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    /* buffers of ranks this call does not have (an earlier call used more contexts) would only hold memory */
+    for (int g = nctx; g < 64; g++) cache_release(g_cache[g]);
     C.err.assign((size_t)nctx, std::string());
     HostBarrier bar(nctx);
     C.bar = &bar;
-    int caller_device = -1;
-    (void)hipGetDevice(&caller_device);
     std::vector<std::thread> th;
     for (int g = 1; g < nctx; g++) th.emplace_back(rank_thread, std::ref(C), g);
     rank_thread(C, 0);

@@ -101,6 +101,49 @@ KERNEL(k_cvt, "v_cvt_f32_ubyte0 %0, %0")
 KERNEL(k_fadd, "v_add_f32 %0, %0, %1")
 KERNEL(k_ffma, "v_fma_f32 %0, %0, %1, %2")
 
+// SGPR-operand instructions in a mix: does it matter whether the two per word sit next to each other (as the kernel's
+// mismatch-bit step has them: v_xor with an SGPR, then v_bitop3 with an SGPR) or are spread among VGPR-only ones?
+#define MIXK(NAME, BODY)                                                                \
+    __global__ __launch_bounds__(64) void NAME(uint32_t *out, int iters)                \
+    {                                                                                   \
+        uint32_t a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 * 11 + 4,      \
+                 a5 = a0 * 13 + 5, a6 = a0 * 17 + 6, a7 = a0 * 19 + 7;                  \
+        const uint32_t b = (blockIdx.x * 2654435761u + 12345u) | 1u, c = (b ^ 0x5bd1e995u) & 31u;            \
+        const uint32_t sg = __builtin_amdgcn_readfirstlane(b), sh = __builtin_amdgcn_readfirstlane(c + 77u);  \
+        for (int it = 0; it < iters; it++) {                                            \
+            _Pragma("unroll") for (int r = 0; r < 8; r++) { BODY }                      \
+        }                                                                               \
+        out[blockIdx.x * 64 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;     \
+    }
+#define SX(A) asm volatile("v_xor_b32 %0, %1, %0" : "+v"(A) : "s"(sg));
+#define SB(A) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf6" : "+v"(A) : "v"(b), "s"(sh));
+#define VB(A) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(A) : "v"(b), "v"(c));
+#define VX(A) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(A) : "v"(c));
+MIXK(k_mix_adjacent, SX(a0) SB(a1) VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+MIXK(k_mix_spread, SX(a0) VB(a2) VB(a3) VX(a4) SB(a1) VB(a5) VX(a6) VB(a7))
+MIXK(k_mix_same_sgpr, asm volatile("v_xor_b32 %0, %1, %0" : "+v"(a0) : "s"(sg)); asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0xf6" : "+v"(a1) : "v"(b), "s"(sg)); VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+MIXK(k_mix_none, VX(a0) VB(a1) VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+MIXK(k_mix_one, SX(a0) VB(a1) VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+MIXK(k_mix_half_adjacent, asm volatile("v_ffbl_b32 %0, %0" : "+v"(a0)); asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a1) : "v"(b)); VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+
+// what ONE half-rate instruction costs among seven full-rate ones (the trips are such mixes)
+#define HMIX(NAME, HOP) MIXK(NAME, asm volatile(HOP : "+v"(a0) : "v"(b), "v"(c) : "vcc"); VB(a1) VB(a2) VB(a3) VX(a4) VB(a5) VX(a6) VB(a7))
+HMIX(k_h1_bcnt, "v_bcnt_u32_b32 %0, %0, %1")
+HMIX(k_h1_ffbl, "v_ffbl_b32 %0, %0")
+HMIX(k_h1_cmp, "v_cmp_ne_u32 vcc, %0, %1")
+HMIX(k_h1_mad, "v_mad_u32_u24 %0, %0, %1, %2")
+HMIX(k_h1_alignbit, "v_alignbit_b32 %0, %0, %1, %2")
+HMIX(k_h1_sad, "v_sad_u32 %0, %0, %1, %2")
+HMIX(k_h1_lshl, "v_lshlrev_b32 %0, 1, %0")
+HMIX(k_h1_min3, "v_min3_u32 %0, %0, %1, %2")
+HMIX(k_h1_mbcnt, "v_mbcnt_lo_u32_b32 %0, -1, %0")
+HMIX(k_h1_lshl_add, "v_lshl_add_u32 %0, %0, 8, %1")
+HMIX(k_h1_mul24, "v_mul_u32_u24 %0, %0, %1")
+HMIX(k_h1_bfe, "v_bfe_u32 %0, %0, 5, 1")
+HMIX(k_h1_add3, "v_add3_u32 %0, %0, %1, %2")
+MIXK(k_h4_mixed, asm volatile("v_ffbl_b32 %0, %0" : "+v"(a0)); VB(a1) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a2) : "v"(b)); VB(a3) asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a4) : "v"(b), "v"(c)); VB(a5) asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a6) : "v"(b), "v"(c)); VB(a7))
+MIXK(k_h8_mixed, asm volatile("v_ffbl_b32 %0, %0" : "+v"(a0)); asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a1) : "v"(b), "v"(c)); asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(a2) : "v"(b)); asm volatile("v_sad_u32 %0, %0, %1, %2" : "+v"(a3) : "v"(b), "v"(c)); asm volatile("v_mad_u32_u24 %0, %0, %1, %2" : "+v"(a4) : "v"(b), "v"(c)); asm volatile("v_lshl_add_u32 %0, %0, 8, %1" : "+v"(a5) : "v"(b)); asm volatile("v_alignbit_b32 %0, %0, %1, %2" : "+v"(a6) : "v"(b), "v"(c)); asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a7) : "v"(b));)
+
 typedef void (*kern_t)(uint32_t *, int);
 
 static int run(const char *name, kern_t k, int per_iter, uint32_t *buf, FILE *js, bool first)
@@ -204,6 +247,27 @@ int main()
     RUN("v_cvt_f32_ubyte0", k_cvt, 64)
     RUN("v_add_f32", k_fadd, 64)
     RUN("v_fma_f32", k_ffma, 64)
+    RUN("mix 8: no SGPR operand", k_mix_none, 64)
+    RUN("mix 8: 1 SGPR-operand instr", k_mix_one, 64)
+    RUN("mix 8: 2 SGPR-operand, adjacent", k_mix_adjacent, 64)
+    RUN("mix 8: 2 SGPR-operand, spread", k_mix_spread, 64)
+    RUN("mix 8: 2 adjacent, same SGPR", k_mix_same_sgpr, 64)
+    RUN("mix 8: 2 half-rate (ffbl, bcnt)", k_mix_half_adjacent, 64)
+    RUN("mix 8: 1 v_bcnt + 7 full", k_h1_bcnt, 64)
+    RUN("mix 8: 1 v_ffbl + 7 full", k_h1_ffbl, 64)
+    RUN("mix 8: 1 v_cmp + 7 full", k_h1_cmp, 64)
+    RUN("mix 8: 1 v_mad_u32_u24 + 7 full", k_h1_mad, 64)
+    RUN("mix 8: 1 v_alignbit + 7 full", k_h1_alignbit, 64)
+    RUN("mix 8: 1 v_sad_u32 + 7 full", k_h1_sad, 64)
+    RUN("mix 8: 1 v_lshlrev + 7 full", k_h1_lshl, 64)
+    RUN("mix 8: 1 v_min3_u32 + 7 full", k_h1_min3, 64)
+    RUN("mix 8: 1 v_mbcnt_lo + 7 full", k_h1_mbcnt, 64)
+    RUN("mix 8: 1 v_lshl_add + 7 full", k_h1_lshl_add, 64)
+    RUN("mix 8: 1 v_mul_u32_u24 + 7 full", k_h1_mul24, 64)
+    RUN("mix 8: 1 v_bfe_u32 + 7 full", k_h1_bfe, 64)
+    RUN("mix 8: 1 v_add3_u32 + 7 full", k_h1_add3, 64)
+    RUN("mix 8: 4 half-rate alternating", k_h4_mixed, 64)
+    RUN("mix 8: 8 different half-rate", k_h8_mixed, 64)
     if (js) { fprintf(js, "}\n"); fclose(js); }
     return 0;
 }
