@@ -126,9 +126,9 @@ def issue_model(workload):
                     "per_shift": {k: w["per_shift"][k] for k in ("full_rate", "sgpr_operand", "half_rate", "cycles")},
                     "per_trip": {k: w["trip"][k] for k in ("full_rate", "sgpr_operand", "half_rate", "cycles")},
                     "note": "frac above prices every VALU instruction alike (peak = one per 2 cycles and SIMD); on gfx950 only "
-                            "v_and/or/xor/add/sub/not/mov/lshrrev/ashrrev/bitop3 on VGPRs issue that fast, everything else and "
-                            "any SGPR operand take about twice as long (profiles/r3_valu_ops.txt). Priced per opcode, the "
-                            "kernel's VALU issue fills this fraction of the SIMD-cycles of its launch."}
+                            "v_and/or/xor/add/sub/not/mov/lshrrev/ashrrev/bitop3 issue that fast, everything else takes about "
+                            "twice as long (profiles/r3_valu_ops.txt). Priced per opcode, the kernel's VALU issue fills this "
+                            "fraction of the SIMD-cycles of its launch."}
     return None
 
 

@@ -27,9 +27,10 @@ LLVM = "/opt/rocm/lib/llvm/bin"
 FULL = {"v_xor_b32", "v_and_b32", "v_or_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_lshrrev_b32", "v_ashrrev_i32",
         "v_not_b32", "v_mov_b32", "v_bitop3_b32", "v_add_f32", "v_fma_f32"}
 # cycles per wave64 instruction and SIMD (profiles/r3_valu_ops.txt).  C_SGPR: a full-rate opcode with an SGPR source costs
-# 4.2 in a stream made of nothing else, 3.3 where VGPR-only instructions sit between them ("kernel mix 2s+6v",
-# profiles/r2_valu_peak_microbench.txt: (8 x 2.69 - 6 x 2.5) / 2), which is how the kernel uses them
-C_FULL, C_SGPR, C_HALF = 2.2, 3.3, 4.2
+# 4.2 in a stream made of nothing else, but NOTHING extra where VGPR-only instructions sit around it ("mix 8: 2 SGPR-operand,
+# adjacent" 2.30-2.33 against 2.30-2.32 without any), which is how the kernel uses them: two per word among twelve others.
+# C_HALF: one half-rate instruction among seven full-rate ones costs 4.0-4.1, four alternating with full-rate ones 3.8 each.
+C_FULL, C_SGPR, C_HALF = 2.2, 2.2, 4.2
 
 
 def disassemble(obj, kernel):
