@@ -22,6 +22,7 @@
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,6 +45,69 @@ constexpr int SVM_MAX_R = 16;      /* samples per thread at the largest size */
 constexpr int SVM_MAX_THREADS = 1024;
 constexpr int SVM_MAX_L = SVM_MAX_THREADS * SVM_MAX_R;
 constexpr double SVM_TAU = 1e-12;
+
+/* Device scratch of the solver calls, kept for the life of the process: a pipeline solves the folds of one subset on a
+ * second stream while the Gram kernel of the next subset runs (gkmqc_amd/gkmsvm.py init_many), and hipMalloc / hipFree
+ * wait for the whole device -- i.e. for that Gram kernel.  A pool, because two workers may solve on one device at
+ * the same time.  gkmsvm_release_cache() frees what is not in use. */
+struct SvmScratch {
+    int device = -1;
+    char *p = nullptr;
+    size_t cap = 0;
+    bool in_use = false;
+};
+static std::mutex g_scratch_mutex;
+static std::vector<SvmScratch *> g_scratch;
+
+static SvmScratch *scratch_acquire(int device, size_t bytes)
+{
+    SvmScratch *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        for (SvmScratch *c : g_scratch)
+            if (!c->in_use && c->device == device && (!b || (c->cap >= bytes && (b->cap < bytes || c->cap < b->cap)))) b = c;
+        if (!b) {
+            b = new SvmScratch();
+            b->device = device;
+            g_scratch.push_back(b);
+        }
+        b->in_use = true;
+    }
+    if (b->cap < bytes) { /* (this thread owns b now) */
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+        const size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc((void **)&b->p, want) != hipSuccess) {
+            std::lock_guard<std::mutex> lock(g_scratch_mutex);
+            b->in_use = false;
+            return nullptr;
+        }
+        b->cap = want;
+    }
+    return b;
+}
+static void scratch_release(SvmScratch *b)
+{
+    if (!b) return;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    b->in_use = false;
+}
+extern "C" void gkmsvm_release_cache(void)
+{
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    int dev = -1;
+    (void)hipGetDevice(&dev);
+    for (SvmScratch *b : g_scratch)
+        if (!b->in_use && b->p) {
+            (void)hipSetDevice(b->device);
+            (void)hipFree(b->p);
+            b->p = nullptr;
+            b->cap = 0;
+        }
+    if (dev >= 0) (void)hipSetDevice(dev);
+}
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct SvmProb {
     const int *idx;
@@ -963,12 +1027,14 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
         }
         h[(size_t)p] = {idx + off[p], (int)l, n0[p], alpha + off[p], grad + off[p], rho + p, iters + p};
     }
-    SvmProb *dprobs = nullptr;
-    SVMCHK(hipMalloc((void **)&dprobs, sizeof(SvmProb) * (size_t)nprob));
+    const size_t probs_bytes = align256(sizeof(SvmProb) * (size_t)nprob);
+    SvmScratch *const scr = scratch_acquire(device, probs_bytes + sizeof(double) * (size_t)n);
+    if (!scr) { g_svm_err = "gkmsvm_train_batch: device scratch"; return 4; }
+    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    SvmProb *const dprobs = (SvmProb *)scr->p;
+    double *const diag = (double *)(scr->p + probs_bytes);
     SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(SvmProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
     SVMCHK(hipStreamSynchronize(stream)); /* h is a host temporary */
-    double *diag = nullptr;
-    SVMCHK(hipMalloc((void **)&diag, sizeof(double) * (size_t)n));
     hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
     /* fewest threads and registers that hold the largest problem: narrower reductions, fewer waves
      * per barrier, no spills (GKM_SVM_SHAPE=<threads>x<samples per thread> overrides, for timing) */
@@ -1014,15 +1080,11 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     SMO_LAUNCH(1024, 16, 2)
     {
         g_svm_err = "GKM_SVM_SHAPE: unsupported shape";
-        (void)hipFree(diag);
-        (void)hipFree(dprobs);
         return 4;
     }
 #undef SMO_LAUNCH
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(diag);
-    (void)hipFree(dprobs);
     if (e != hipSuccess) return svm_fail("k_smo", e);
     return 0;
 }
@@ -1050,9 +1112,12 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         }
     }
     /* scratch: 6 int, 5 double, 2 float arrays of `total` entries */
-    char *scratch = nullptr;
     const size_t per = 6 * sizeof(int) + 5 * sizeof(double) + 2 * sizeof(float);
-    SVMCHK(hipMalloc((void **)&scratch, per * (size_t)total + 64));
+    const size_t state_bytes = align256(per * (size_t)total + 64), probs_bytes = align256(sizeof(GenProb) * (size_t)nprob);
+    SvmScratch *const scr = scratch_acquire(device, state_bytes + probs_bytes + sizeof(double) * (size_t)n);
+    if (!scr) { g_svm_err = "gkmsvm_train_batch_general: device scratch"; return 4; }
+    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    char *const scratch = scr->p;
     double *d0 = (double *)scratch;
     int *i0 = (int *)(d0 + 5 * total);
     float *f0 = (float *)(i0 + 6 * total);
@@ -1067,11 +1132,9 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         g.fg = i0 + 4 * total + o; g.fy = i0 + 5 * total + o;
         g.Qi = f0 + o; g.Qj = f0 + total + o;
     }
-    GenProb *dprobs = nullptr;
-    double *diag = nullptr;
-    hipError_t e = hipMalloc((void **)&dprobs, sizeof(GenProb) * (size_t)nprob);
-    if (e == hipSuccess) e = hipMalloc((void **)&diag, sizeof(double) * (size_t)n);
-    if (e == hipSuccess) e = hipMemcpyAsync(dprobs, h.data(), sizeof(GenProb) * (size_t)nprob, hipMemcpyHostToDevice, stream);
+    GenProb *const dprobs = (GenProb *)(scratch + state_bytes);
+    double *const diag = (double *)(scratch + state_bytes + probs_bytes);
+    hipError_t e = hipMemcpyAsync(dprobs, h.data(), sizeof(GenProb) * (size_t)nprob, hipMemcpyHostToDevice, stream);
     if (e == hipSuccess) e = hipStreamSynchronize(stream); /* h is a host temporary */
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
@@ -1086,9 +1149,6 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
     }
-    (void)hipFree(diag);
-    (void)hipFree(dprobs);
-    (void)hipFree(scratch);
     if (e != hipSuccess) return svm_fail("k_smo_general", e);
     return 0;
 }
@@ -1112,14 +1172,15 @@ extern "C" int gkmsvm_decision_batch(int device, const double *K, int64_t ld, in
         if (nt > maxtest) maxtest = nt;
     }
     if (maxtest == 0) return 0;
-    DecProb *dprobs = nullptr;
-    SVMCHK(hipMalloc((void **)&dprobs, sizeof(DecProb) * (size_t)nprob));
+    SvmScratch *const scr = scratch_acquire(device, sizeof(DecProb) * (size_t)nprob);
+    if (!scr) { g_svm_err = "gkmsvm_decision_batch: device scratch"; return 4; }
+    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    DecProb *const dprobs = (DecProb *)scr->p;
     SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(DecProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_decision, dim3((unsigned)((maxtest + 127) / 128), (unsigned)nprob), dim3(128), 0, stream, K, ld,
                        dprobs);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    (void)hipFree(dprobs);
     if (e != hipSuccess) return svm_fail("k_decision", e);
     return 0;
 }

@@ -91,13 +91,14 @@ def _svm_fold(job):
     return auc
 
 
-def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs):
-    """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p]."""
+def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch=None):
+    """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p].
+    about_to_launch: see svmcv.crossValidate (only the GPU-resident path calls it)."""
     if not isinstance(_kmat, np.ndarray):      # torch CUDA tensor: the matrix stays in HBM
         from . import svmcv
         ncv_ = max(2, int(args_svm[4]))
         if (n_pseqs + n_nseqs) * (ncv_ - 1) / ncv_ <= svmcv.MAX_FOLD_SAMPLES:
-            return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs)
+            return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch)
         logging.warning("folds of more than %d samples: cross-validation with scikit-learn on the host",
                         svmcv.MAX_FOLD_SAMPLES)
         _kmat = _kmat.cpu().numpy()
@@ -158,6 +159,11 @@ def _init_many_on(pairs, args, gpu, slot):
     results = [None] * len(pairs)
     errors = []
     handoff = queue.Queue(maxsize=1)     # at most one finished matrix waits while the next one is computed
+    # Launch order: the solver's workgroups are few and big (1024 threads, ~100 KB of LDS each), the Gram kernel's many
+    # and small; once the Gram kernel of the next subset owns every CU the solver waits for room and the two barely
+    # overlap (measured: 512 ms per subset against 522 one after the other).  So the next Gram kernel is held back
+    # until the solver of this subset is on its way: it then takes the CUs it needs first and the Gram kernel the rest.
+    solver_out = [threading.Event() for _ in pairs]
 
     def consumer():
         while True:
@@ -166,16 +172,19 @@ def _init_many_on(pairs, args, gpu, slot):
                 return
             s, K, n_pos, n_neg = item
             if errors:
+                solver_out[s].set()
                 continue
             try:
                 with torch.cuda.stream(cv_stream):
                     K.record_stream(cv_stream)
                     logging.info("%s: svm training", pairs[s][0])
-                    auc, std = crossValidate(args_svm, K, n_pos, n_neg)
+                    auc, std = crossValidate(args_svm, K, n_pos, n_neg, about_to_launch=solver_out[s].set)
                     cv_stream.synchronize()
                 results[s] = (auc, std, n_pos)
             except BaseException as e:      # re-raised by the calling thread
                 errors.append(e)
+            finally:
+                solver_out[s].set()
 
     th = threading.Thread(target=consumer)
     th.start()
@@ -194,6 +203,7 @@ def _init_many_on(pairs, args, gpu, slot):
                 gram_stream.synchronize()
             handoff.put((s, K, n_pos, n_neg))
             del K
+            solver_out[s].wait()         # (the FASTA files of the next subset are read after this, a few ms of margin)
     finally:
         handoff.put(None)
         th.join()

@@ -38,6 +38,7 @@ def _lib():
         L.gkmsvm_decision_batch.restype = i32
         L.gkmsvm_decision_batch.argtypes = (i32, vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp)
         L.gkmsvm_last_error.restype = ctypes.c_char_p
+        L.gkmsvm_release_cache.restype = None
         L._svm_bound = True
     return L
 
@@ -69,7 +70,7 @@ class FoldSolutions:
         return -(a[sv] * ysign[sv]), self.idx[f][sv]
 
 
-def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False):
+def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False, about_to_launch=None):
     """Solve one C-SVC per entry of `trains` (index arrays into the symmetric torch CUDA fp64
     matrix K) concurrently.  Returns (FoldSolutions, device handles for `decision_values`).
     `shrinking`: LIBSVM's shrinking heuristic (scikit-learn `SVC(shrinking=True)`); it and folds of more
@@ -92,6 +93,8 @@ def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False):
         d_grad = torch.empty_like(d_alpha)
         d_rho = torch.empty(len(idx), dtype=torch.float64, device=dev)
         d_it = torch.empty(len(idx), dtype=torch.int32, device=dev)
+        if about_to_launch is not None:
+            about_to_launch()     # everything on the host is done: the solver kernel goes out within microseconds
         if shrinking or max(len(i) for i in idx) > FAST_FOLD_SAMPLES:
             rc = L.gkmsvm_train_batch_general(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx),
                                               d_idx.data_ptr(), off.ctypes.data, n0.ctypes.data, float(C), float(tol),
@@ -145,9 +148,11 @@ def device_block(K, rows, cols):
     return K.index_select(0, r).index_select(1, c)
 
 
-def crossValidate(args_svm, K, n_pseqs, n_nseqs):
+def crossValidate(args_svm, K, n_pseqs, n_nseqs, about_to_launch=None):
     """Same arguments and result as the reference's `crossValidate` (scripts/gkmsvm.py:127-176)
-    with `K` a symmetric torch CUDA matrix: (mean AUC, std AUC) over ncv x repeats folds."""
+    with `K` a symmetric torch CUDA matrix: (mean AUC, std AUC) over ncv x repeats folds.
+    about_to_launch: called once, right before the solver kernel is enqueued (init_many holds the next subset's Gram
+    kernel back until then, so that the solver's few big workgroups find the CUs they need)."""
     from sklearn.metrics import roc_auc_score
     from sklearn.model_selection import StratifiedKFold
     regularization, precision, shrinking, _cache, ncv, repeats, fast_estimation, random_seeds = args_svm[:8]
@@ -173,7 +178,7 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
     u_trains = [trains[u_of[w]] for w in uniq]
     u_tests = [tests[u_of[w]] for w in uniq]
     logging.info("cross-validation on the GPU: %d folds (%d distinct)", len(trains), len(uniq))
-    sol, handles = train_folds(K, u_trains, y, regularization, precision, bool(shrinking))
+    sol, handles = train_folds(K, u_trains, y, regularization, precision, bool(shrinking), about_to_launch)
     scores = decision_values(K, handles, u_tests)
     capped = [f for f in range(len(u_trains)) if sol.iters[f] < 0]
     if capped:   # not converged within 10^7 iterations: the reference's solver has no cap, so use it for these folds
@@ -190,8 +195,8 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs):
     for f, (test, score) in enumerate(zip(u_tests, scores)):
         auc = roc_auc_score(y[test], score)
         nu = np.sum(sol.alpha[f]) / len(u_trains[f])
-        logging.info("SVC training and validation; nu = %.3f, AUC = %.3f, %d iterations", nu, auc, abs(int(sol.iters[f])))
+        logging.info("fold %d solved on the GPU: nu %.3f, AUC %.3f, %d iterations", f, nu, auc, abs(int(sol.iters[f])))
         u_auc.append(auc)
     aucs = [u_auc[w] for w in which]
-    logging.info("done cross-validation.")
+    logging.info("cross-validation finished")
     return (np.mean(aucs), np.std(aucs))

@@ -67,6 +67,12 @@ int gkmsvm_decision_batch(int device, const double *K, int64_t ld, int nprob, co
 
 const char *gkmsvm_last_error(void);
 
+/* The calls above keep their device scratch (problem descriptors, the matrix diagonal, the general solver's state) in a
+ * per-process pool instead of allocating and freeing it per call: hipMalloc / hipFree wait for the whole device, i.e. for
+ * the Gram kernel of the next subset that a pipeline runs beside the solver (gkmqc_amd/gkmsvm.py init_many).  This frees
+ * what is not in use (optional). */
+void gkmsvm_release_cache(void);
+
 #ifdef __cplusplus
 }
 #endif

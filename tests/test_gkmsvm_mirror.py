@@ -72,6 +72,25 @@ def test_init_writes_the_eval_line(built, tmp_path):
 
 
 @pytest.mark.gpu
+def test_solver_announces_its_launch(built):
+    """init_many holds the next subset's Gram kernel back until the solver of the current one is about to be enqueued
+    (its few big workgroups would otherwise wait for room): the hook is called exactly once, before the result exists,
+    and the solver calls keep their device scratch (no hipMalloc / hipFree beside a running Gram kernel)."""
+    from gkmqc_amd import gkmsvm
+    case = EXPECTED["wgkm_L10"]
+    K, n_pos, n_neg = gkmsvm.computeGkmKernel(_args_gkm(case), resident=True)
+    calls = []
+    auc, std = gkmsvm.crossValidate(list(case["args_svm"]), K, n_pos, n_neg, about_to_launch=lambda: calls.append(len(calls)))
+    assert calls == [0]
+    assert abs(auc - case["auc_mean"]) < 1e-12 and abs(std - case["auc_std"]) < 1e-12
+    auc2, _ = gkmsvm.crossValidate(list(case["args_svm"]), K, n_pos, n_neg)      # pooled scratch reused
+    assert auc2 == auc
+    from gkmqc_amd import svmcv
+    svmcv._lib().gkmsvm_release_cache()
+    assert gkmsvm.crossValidate(list(case["args_svm"]), K, n_pos, n_neg)[0] == auc
+
+
+@pytest.mark.gpu
 def test_init_many_overlaps_and_matches_init(built, tmp_path):
     """Several subsets in a row, the cross-validation of one on a second stream beside the matrix of the
     next: same AUCs and the same eval lines as one `init` per subset."""
