@@ -91,14 +91,14 @@ def _svm_fold(job):
     return auc
 
 
-def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch=None):
+def crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch=None, plan=None):
     """args_svm = [C, tol, shrinking, cache_size, ncv, repeats, fast_estimation, random_seeds, p].
-    about_to_launch: see svmcv.crossValidate (only the GPU-resident path calls it)."""
+    about_to_launch, plan: see svmcv.crossValidate (only the GPU-resident path uses them)."""
     if not isinstance(_kmat, np.ndarray):      # torch CUDA tensor: the matrix stays in HBM
         from . import svmcv
         ncv_ = max(2, int(args_svm[4]))
         if (n_pseqs + n_nseqs) * (ncv_ - 1) / ncv_ <= svmcv.MAX_FOLD_SAMPLES:
-            return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch)
+            return svmcv.crossValidate(args_svm, _kmat, n_pseqs, n_nseqs, about_to_launch, plan)
         logging.warning("folds of more than %d samples: cross-validation with scikit-learn on the host",
                         svmcv.MAX_FOLD_SAMPLES)
         _kmat = _kmat.cpu().numpy()
@@ -166,6 +166,8 @@ def _init_many_on(pairs, args, gpu, slot):
     solver_out = [threading.Event() for _ in pairs]
 
     def consumer():
+        from . import svmcv
+        plan = None
         while True:
             item = handoff.get()
             if item is None:
@@ -178,9 +180,12 @@ def _init_many_on(pairs, args, gpu, slot):
                 with torch.cuda.stream(cv_stream):
                     K.record_stream(cv_stream)
                     logging.info("%s: svm training", pairs[s][0])
-                    auc, std = crossValidate(args_svm, K, n_pos, n_neg, about_to_launch=solver_out[s].set)
+                    auc, std = crossValidate(args_svm, K, n_pos, n_neg, about_to_launch=solver_out[s].set, plan=plan)
                     cv_stream.synchronize()
                 results[s] = (auc, std, n_pos)
+                # the next subset's folds, drawn while its matrix is being computed (the subsets of an evaluate run have
+                # the same sizes; other sizes are planned when they arrive)
+                plan = svmcv.plan_folds(args_svm, n_pos, n_neg) if s + 1 < len(pairs) else None
             except BaseException as e:      # re-raised by the calling thread
                 errors.append(e)
             finally:

@@ -148,16 +148,12 @@ def device_block(K, rows, cols):
     return K.index_select(0, r).index_select(1, c)
 
 
-def crossValidate(args_svm, K, n_pseqs, n_nseqs, about_to_launch=None):
-    """Same arguments and result as the reference's `crossValidate` (scripts/gkmsvm.py:127-176)
-    with `K` a symmetric torch CUDA matrix: (mean AUC, std AUC) over ncv x repeats folds.
-    about_to_launch: called once, right before the solver kernel is enqueued (init_many holds the next subset's Gram
-    kernel back until then, so that the solver's few big workgroups find the CUs they need)."""
-    from sklearn.metrics import roc_auc_score
+def plan_folds(args_svm, n_pseqs, n_nseqs):
+    """The host-side half of `crossValidate` that does not need the matrix: labels and the ncv x repeats stratified folds
+    (the reference's splitter and seeding, scripts/gkmsvm.py:134-150), equal folds solved once.  ~10 ms of scikit-learn
+    at 10 000 sequences -- a pipeline draws the next subset's folds while the GPU is still busy with this one's."""
     from sklearn.model_selection import StratifiedKFold
-    regularization, precision, shrinking, _cache, ncv, repeats, fast_estimation, random_seeds = args_svm[:8]
-    if fast_estimation != 0:
-        raise NotImplementedError("fast AUC estimation is dead code in the reference (its regressor is never loaded)")
+    ncv, repeats, random_seeds = args_svm[4], args_svm[5], args_svm[7]
     if random_seeds is not None and random_seeds < 0:
         random_seeds = None
     seqids = ["p%4d" % i for i in range(n_pseqs)] + ["n%4d" % i for i in range(n_nseqs)]
@@ -175,9 +171,24 @@ def crossValidate(args_svm, K, n_pseqs, n_nseqs, about_to_launch=None):
         which.append(first.setdefault(train.tobytes(), len(first)))
     uniq = sorted(set(which))
     u_of = {w: [f for f in range(len(trains)) if which[f] == w][0] for w in uniq}
-    u_trains = [trains[u_of[w]] for w in uniq]
-    u_tests = [tests[u_of[w]] for w in uniq]
-    logging.info("cross-validation on the GPU: %d folds (%d distinct)", len(trains), len(uniq))
+    return dict(sizes=(n_pseqs, n_nseqs), y=y, n_folds=len(trains), which=which,
+                u_trains=[trains[u_of[w]] for w in uniq], u_tests=[tests[u_of[w]] for w in uniq])
+
+
+def crossValidate(args_svm, K, n_pseqs, n_nseqs, about_to_launch=None, plan=None):
+    """Same arguments and result as the reference's `crossValidate` (scripts/gkmsvm.py:127-176)
+    with `K` a symmetric torch CUDA matrix: (mean AUC, std AUC) over ncv x repeats folds.
+    about_to_launch: called once, right before the solver kernel is enqueued (init_many holds the next subset's Gram
+    kernel back until then, so that the solver's few big workgroups find the CUs they need).
+    plan: the folds drawn ahead of time by `plan_folds` for these sizes (otherwise drawn here)."""
+    from sklearn.metrics import roc_auc_score
+    regularization, precision, shrinking, _cache, _ncv, _repeats, fast_estimation = args_svm[:7]
+    if fast_estimation != 0:
+        raise NotImplementedError("fast AUC estimation is dead code in the reference (its regressor is never loaded)")
+    if plan is None or plan["sizes"] != (n_pseqs, n_nseqs):
+        plan = plan_folds(args_svm, n_pseqs, n_nseqs)
+    y, which, u_trains, u_tests = plan["y"], plan["which"], plan["u_trains"], plan["u_tests"]
+    logging.info("cross-validation on the GPU: %d folds (%d distinct)", plan["n_folds"], len(u_trains))
     sol, handles = train_folds(K, u_trains, y, regularization, precision, bool(shrinking), about_to_launch)
     scores = decision_values(K, handles, u_tests)
     capped = [f for f in range(len(u_trains)) if sol.iters[f] < 0]
