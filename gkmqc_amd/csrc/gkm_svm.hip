@@ -610,6 +610,7 @@ struct GenProb {
 };
 
 constexpr int GEN_T = 1024;
+constexpr int GEN_U = 8; /* positions of a thread whose loads are in flight together */
 constexpr int GEN_NW = GEN_T / 64;
 
 struct GenSel {
@@ -681,7 +682,25 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     auto q_row = [&](int t, float *out, int k0, int k1) {
         const double *Kt = K + (int64_t)gidx[t] * ld;
         const int yt = ys[t];
-        for (int k = k0 + tid; k < k1; k += GEN_T) out[k] = (float)((double)(yt * ys[k]) * Kt[gidx[k]]);
+        /* GEN_U positions of a thread at a time, the loads of one kind issued together: the state lives in global
+         * memory (L2), and a loop that uses each value as soon as it is loaded pays one round trip per position */
+        for (int kb = k0 + tid; kb < k1; kb += GEN_T * GEN_U) {
+            int gi[GEN_U], yk[GEN_U];
+            double kv[GEN_U];
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T, kc = k < k1 ? k : kb;
+                gi[u] = gidx[kc];
+                yk[u] = ys[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) kv[u] = Kt[gi[u]];
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T;
+                if (k < k1) out[k] = (float)((double)(yt * yk[u]) * kv[u]);
+            }
+        }
     };
 
     int active = l;
@@ -731,12 +750,24 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     auto select = [&](int &out_i, int &out_j) -> int {
         double gm = -INFINITY;
         int gi = -1;
-        for (int k = tid; k < active; k += GEN_T) {
-            const double a = alpha[k], g = G[k];
-            if (ys[k] == +1) {
-                if (!is_upper(a) && -g >= gm) { gm = -g; gi = k; }
-            } else {
-                if (!is_lower(a) && g >= gm) { gm = g; gi = k; }
+        for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
+            double av[GEN_U], gv[GEN_U];
+            int yv[GEN_U];
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T, kc = k < active ? k : kb;
+                av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) { /* ascending k inside the thread: ">=" keeps LIBSVM's last-of-equals */
+                const int k = kb + u * GEN_T;
+                if (k >= active) break;
+                const double a = av[u], g = gv[u];
+                if (yv[u] == +1) {
+                    if (!is_upper(a) && -g >= gm) { gm = -g; gi = k; }
+                } else {
+                    if (!is_lower(a) && g >= gm) { gm = g; gi = k; }
+                }
             }
         }
         block_select<false>(gm, gi, sel_s);
@@ -748,14 +779,26 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         const double yi2 = 2.0 * (double)ys[i];
         double gm2 = -INFINITY, omin = INFINITY;
         int gj = -1;
-        for (int k = tid; k < active; k += GEN_T) { /* (each thread reads back the Q_i entries it wrote) */
-            const double a = alpha[k], g = G[k];
-            if (ys[k] == +1) {
+        for (int kb = tid; kb < active; kb += GEN_T * GEN_U) { /* (each thread reads back the Q_i entries it wrote) */
+          double av[GEN_U], gv[GEN_U], qdv[GEN_U];
+          float qiv[GEN_U];
+          int yv[GEN_U];
+#pragma unroll
+          for (int u = 0; u < GEN_U; u++) {
+              const int k = kb + u * GEN_T, kc = k < active ? k : kb;
+              av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc]; qdv[u] = QD[kc]; qiv[u] = Qi[kc];
+          }
+#pragma unroll
+          for (int u = 0; u < GEN_U; u++) {
+            const int k = kb + u * GEN_T;
+            if (k >= active) break;
+            const double a = av[u], g = gv[u];
+            if (yv[u] == +1) {
                 if (!is_lower(a)) {
                     const double grad_diff = gm + g;
                     if (g >= gm2) gm2 = g;
                     if (grad_diff > 0) {
-                        const double quad_coef = QDi + QD[k] - yi2 * (double)Qi[k];
+                        const double quad_coef = QDi + qdv[u] - yi2 * (double)qiv[u];
                         const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
                         if (obj_diff <= omin) { gj = k; omin = obj_diff; }
                     }
@@ -765,12 +808,13 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                     const double grad_diff = gm - g;
                     if (-g >= gm2) gm2 = -g;
                     if (grad_diff > 0) {
-                        const double quad_coef = QDi + QD[k] + yi2 * (double)Qi[k];
+                        const double quad_coef = QDi + qdv[u] + yi2 * (double)qiv[u];
                         const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
                         if (obj_diff <= omin) { gj = k; omin = obj_diff; }
                     }
                 }
             }
+          }
         }
         const double Gmax2 = block_max(gm2, max_s);
         block_select<true>(omin, gj, sel_s);
@@ -907,7 +951,20 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         }
         const double dai = ai - old_ai, daj = aj - old_aj;
         __syncthreads(); /* everybody has read G[i], G[j], alpha[i], alpha[j] */
-        for (int k = tid; k < active; k += GEN_T) G[k] += (double)Qi[k] * dai + (double)Qj[k] * daj;
+        for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
+            double gv[GEN_U];
+            float qiv[GEN_U], qjv[GEN_U];
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T, kc = k < active ? k : kb;
+                gv[u] = G[kc]; qiv[u] = Qi[kc]; qjv[u] = Qj[kc];
+            }
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T;
+                if (k < active) G[k] = gv[u] + ((double)qiv[u] * dai + (double)qjv[u] * daj);
+            }
+        }
         if (tid == 0) { alpha[i] = ai; alpha[j] = aj; }
         if (shrinking) { /* G_bar only matters to reconstruct_gradient */
             const bool ui = is_upper(old_ai), uj = is_upper(old_aj);
