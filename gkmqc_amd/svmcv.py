@@ -104,6 +104,13 @@ def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False, about_to_launch=
             rc = L.gkmsvm_train_batch(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx), d_idx.data_ptr(),
                                       off.ctypes.data, n0.ctypes.data, float(C), float(tol), d_alpha.data_ptr(),
                                       d_grad.data_ptr(), d_rho.data_ptr(), d_it.data_ptr(), stream)
+            if rc:   # e.g. a launch shape the device refuses (the big shapes take up to 144 KB of LDS): the general
+                     # solver needs none of that and returns the same bits without shrinking
+                logging.warning("k_smo failed (%s): solving with the general GPU solver", L.gkmsvm_last_error().decode())
+                rc = L.gkmsvm_train_batch_general(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx),
+                                                  d_idx.data_ptr(), off.ctypes.data, n0.ctypes.data, float(C), float(tol),
+                                                  0, d_alpha.data_ptr(), d_grad.data_ptr(), d_rho.data_ptr(),
+                                                  d_it.data_ptr(), stream)
         if rc:
             raise SvmError("gkmsvm_train_batch: %s" % L.gkmsvm_last_error().decode())
         alpha = d_alpha.cpu().numpy()
