@@ -35,6 +35,27 @@ def test_cross_validate_matches_reference_on_cpu(built, name):
     assert abs(auc - case["auc_mean"]) < 1e-9 and abs(std - case["auc_std"]) < 1e-9
 
 
+def test_plan_folds_follows_the_reference_seeding():
+    """The folds a pipeline draws ahead of time are the reference's (scripts/gkmsvm.py:134-150): StratifiedKFold with
+    shuffle and the SAME random_state for every repeat -- so a fixed seed repeats the same ncv folds (solved once, counted
+    `repeats` times) and no seed draws ncv x repeats different ones; every fold is stratified and a partition."""
+    from sklearn.model_selection import StratifiedKFold
+    from gkmqc_amd import svmcv
+    args = [1.0, 0.001, 0, 512, 5, 10, 0, 7, 1]
+    plan = svmcv.plan_folds(args, 60, 90)
+    assert plan["sizes"] == (60, 90) and plan["n_folds"] == 50 and len(plan["u_trains"]) == 5
+    assert plan["which"] == [0, 1, 2, 3, 4] * 10
+    y = plan["y"]
+    assert (y[:60] == 1).all() and (y[60:] == 0).all()
+    want = list(StratifiedKFold(n_splits=5, shuffle=True, random_state=7).split(np.zeros(150), y))
+    for (tr, te), ptr, pte in zip(want, plan["u_trains"], plan["u_tests"]):
+        assert np.array_equal(tr, ptr) and np.array_equal(te, pte)
+        assert len(np.intersect1d(ptr, pte)) == 0 and len(ptr) + len(pte) == 150
+        assert int(y[pte].sum()) == 12 and len(pte) == 30                      # stratified: 60/5 positives per test fold
+    free = svmcv.plan_folds([1.0, 0.001, 0, 512, 5, 10, 0, -1, 1], 60, 90)       # -1 = no seed, as the reference's default
+    assert free["n_folds"] == 50 and len(free["u_trains"]) > 5
+
+
 def test_fast_estimation_is_rejected(built):
     from gkmqc_amd import gkmsvm
     with pytest.raises(NotImplementedError):
