@@ -173,3 +173,29 @@ def test_device_selection_is_validated(dev, monkeypatch, value):
         o = dev.gkmOpt(4, 11, 7, 3, 50, 50.0, 1.0, helpers.QUIRK_POS.encode(), helpers.QUIRK_NEG.encode(), 1, 0)
         rc, kmat, sizes = _call_wrapper(dev, o)
         assert rc != 0 and (kmat == -7.0).all() and (sizes == -1).all()
+
+
+def test_issue_model_reads_the_hot_kernel(built):
+    """tools/issue_model.py (the analysis behind DESIGN.md §5a and `roofline.issue_model`) must keep finding, in the ISA of
+    the product build, the counting loop (four shifts per block, ~130 VALU instructions per shift, the two SGPR-operand
+    instructions per word among them) and the trips (one copy per push site + the final partial one), and must price the
+    half-rate opcodes apart from the full-rate ones."""
+    import importlib.util
+    import shutil
+    obj = os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_device.o")
+    if not (os.path.exists(obj) and shutil.which("llvm-objdump", path="/opt/rocm/lib/llvm/bin")):
+        pytest.skip("needs the built device object and llvm-objdump")
+    spec = importlib.util.spec_from_file_location("issue_model", os.path.join(ROOT, "tools", "issue_model.py"))
+    im = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(im)
+    assert im.classify("v_bitop3_b32 v1, v2, v3, v4 bitop3:0x96") == "F"
+    assert im.classify("v_xor_b32_e32 v1, s5, v3") == "S"
+    assert im.classify("v_lshlrev_b32_e32 v1, 1, v3") == "H" and im.classify("v_bcnt_u32_b32 v1, v2, v3") == "H"
+    assert im.classify("s_add_i32 s1, s2, s3") is None and im.classify("ds_read_b32 v1, v2") is None
+    for kernel, words in (([10, 11, 3, 0], 10), ([10, 10, 3, 3], 10)):
+        m = im.analyse(obj, kernel, 4)
+        per_shift = m["per_shift"]["full_rate"] + m["per_shift"]["sgpr_operand"] + m["per_shift"]["half_rate"]
+        assert 120 <= per_shift <= 145, per_shift
+        assert m["per_shift"]["sgpr_operand"] >= 2 * words            # the column's two bit planes per word
+        assert m["trip_copies"] >= 9 and 50 <= m["trip"]["full_rate"] + m["trip"]["sgpr_operand"] + m["trip"]["half_rate"] <= 80
+        assert m["trip"]["half_rate"] > m["trip"]["full_rate"] * 0.8   # the trips are where the half-rate opcodes are
