@@ -9,10 +9,19 @@ norms, unit diagonal) on every rank.
     python bench.py [--gpus N --steps K --warmup W] [--workload c2|peaks|c3|c5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself
-(fresh child processes, one per GPU, before anything in this process has touched the GPU) and relays
-rank 0's line.  `--assembly cabi` instead runs the one-process entry of the C ABI
-(gkmhip_gram_allgather: one host thread per device, RCCL all-gather) as a cross-check.
+N > 1 (`--assembly auto`, the default) measures BOTH multi-GPU drivers, each in fresh processes with a timeout:
+  primary      the product's own entry behind the C ABI, gkmhip_gram_allgather (ONE process, one host thread per
+               device, RCCL all-gather of the packed row slabs) -- run as a child `--assembly cabi` of rank 0 before
+               any rank has touched a GPU;
+  cross-check  one process per GPU, torch.distributed (backend nccl = RCCL) all_gather_into_tensor: the ranks the
+               launcher started (or, without a launcher, N ranks this script starts itself) -> `also.torch_dist`.
+If the primary fails, times out or fails its parity check the line says so (`cabi_error`) and carries the torch
+numbers instead.  `--assembly torch|cabi` runs one of them alone.
+
+PARITY GATE: after the timed region the matrix the last timed step produced is copied to the host and the SHA-256 of
+its strict lower triangle (the cells the reference writes, src/gkmkern_pylib.c:83,218-221) is compared with the digest
+of the reference's own matrix (tests/golden/<workload>_full_digest.npz) -- on every rank's / device's copy for N > 1.
+A mismatch sets `value` aside (`parity_failed`, exit code 3).
 
 Rank 0 prints ONE JSON line.  `value` = N(N-1)/2 pairs / (max-over-ranks seconds per step).
 The total work is fixed as the GPU count grows (the N x N matrix is sharded by row block), so
@@ -142,6 +151,79 @@ def measured_valu_peak():
     return None, None
 
 
+# workload -> digest fixture of the REFERENCE's own full-size matrix (tests/golden/make_golden.py --full)
+PARITY_FIXTURES = {"c2": "c2_full_digest.npz", "c3": "c3_full_digest.npz", "c5": "c5_full_digest.npz",
+                   "peaks": "c4_full_digest.npz"}
+
+
+def parity_check(workload, custom, K):
+    """The parity gate of the line: K = the n x n matrix (numpy, host) the timed step produced.
+    SHA-256 of the strict lower triangle in row-major order -- exactly the cells the reference writes
+    (src/gkmkern_pylib.c:83) -- against the digest of the reference's own matrix, plus the largest relative error
+    on the fixture's 4 000 sampled cells.  Data only: nothing under oracle/ is touched."""
+    import numpy as np
+    n = K.shape[0]
+    golden = os.path.join(ROOT, "tests", "golden")
+    if custom or workload not in PARITY_FIXTURES:
+        if workload == "c1" and not custom and os.path.exists(os.path.join(golden, "synthetic_expected.npz")):
+            want = np.load(os.path.join(golden, "synthetic_expected.npz"))["c1_full_K"]
+            i, j = np.tril_indices(n, -1)
+            got = K[i, j]
+            err = float(np.max(np.abs(got - want) / np.maximum(np.abs(want), 1e-300)))
+            return {"fixture": "tests/golden/synthetic_expected.npz:c1_full_K", "sha256_matches_reference": None,
+                    "max_rel_err": err, "ok": err < 1e-6}
+        return {"fixture": None, "sha256_matches_reference": None, "ok": None,
+                "why": "no reference digest for this problem (custom sizes, or a workload without a fixture)"}
+    path = os.path.join(golden, PARITY_FIXTURES[workload])
+    if not os.path.exists(path):
+        return {"fixture": None, "sha256_matches_reference": None, "ok": None, "why": "fixture file missing: " + path}
+    z = np.load(path)
+    h = hashlib.sha256()
+    for a in range(1, n):
+        h.update(memoryview(K[a, :a]))
+    same = h.digest() == z["sha256"].tobytes()
+    idx = z["sample_idx"].astype(np.int64)
+    a = ((1.0 + np.sqrt(1.0 + 8.0 * idx)) / 2.0).astype(np.int64)
+    a = np.where(a * (a - 1) // 2 > idx, a - 1, a)
+    a = np.where((a + 1) * a // 2 <= idx, a + 1, a)
+    j = idx - a * (a - 1) // 2
+    want = z["sample_val"]
+    err = float(np.max(np.abs(K[a, j] - want) / np.maximum(np.abs(want), 1e-300)))
+    return {"fixture": "tests/golden/" + PARITY_FIXTURES[workload], "sha256_matches_reference": bool(same),
+            "max_rel_err_sample": err, "sampled_cells": int(len(idx)),
+            "cells": "strict lower triangle, row-major: what the reference writes (src/gkmkern_pylib.c:83)",
+            "ok": bool(same)}
+
+
+def parity_of_device_matrix(args, full):
+    """D2H of a torch matrix + parity_check."""
+    K = full.cpu().numpy()
+    try:
+        return parity_check(args.workload, args.custom, K)
+    finally:
+        del K
+
+
+def merge_parity(per_copy):
+    """One `parity` object for a line from the checks of every rank's / device's assembled copy."""
+    if not per_copy:
+        return None
+    out = dict(per_copy[0])
+    oks = [p.get("ok") for p in per_copy]
+    out["checked_copies"] = len(per_copy)
+    if any(o is None for o in oks):
+        out["ok"] = None
+    else:
+        out["ok"] = all(oks)
+        if out.get("sha256_matches_reference") is not None:
+            out["sha256_matches_reference"] = all(p.get("sha256_matches_reference") for p in per_copy)
+            out["sha256_matches_reference_per_copy"] = [p.get("sha256_matches_reference") for p in per_copy]
+        for key in ("max_rel_err_sample", "max_rel_err"):
+            if key in out:
+                out[key] = max(p[key] for p in per_copy)
+    return out
+
+
 def make_problem(args):
     from gkmqc_amd import synth
     if args.generator == "peaks":
@@ -237,7 +319,7 @@ def end_to_end(args, dev):
     return out
 
 
-def multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus):
+def multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus, bytes_per_rank=None, bytes_full_width=None):
     """Roofline fields of an N > 1 line from (a) SQ_INSTS_VALU of the hash-matched ONE-GPU summary of the same
     workload and (b) what every rank measured itself.  The instructions executed per l-mer comparison do not
     depend on which rank computes a row, so the whole job executes what the one-GPU launch executed; it is spread
@@ -258,6 +340,12 @@ def multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus):
             "allgather_ms": max(r["allgather_ms"] for r in per_rank),
             "allgather_ms_per_rank": [r["allgather_ms"] for r in per_rank],
             "assemble_ms": max(r["assemble_ms"] for r in per_rank)})
+    if bytes_per_rank is not None:
+        # what every rank RECEIVES from its peers per matrix (packed row slabs: row a = a + 1 doubles), what full-width
+        # rows cost in round 3, and the rate the collectives sustained on their stream (sum over the chunks)
+        ag = out.get("allgather_ms")
+        out.update({"allgather_bytes_per_rank": int(bytes_per_rank), "allgather_bytes_full_width_rows": bytes_full_width,
+                    "allgather_GBps_per_rank": (bytes_per_rank / (ag * 1e-3) / 1e9) if ag else None})
     return out
 
 
@@ -296,8 +384,9 @@ def side_workload(name, dev, steps=3):
         kern_s = float(np.mean(kms)) * 1e-3
         pmc, src = pmc_summary(name)
         insts = pmc["per_launch"].get("SQ_INSTS_VALU") if pmc else None
+        parity = parity_of_device_matrix(a, full)
         return {"workload": a.label, "n_sequences": n, "length": a.length_range or a.length, "L": a.L, "k": a.k, "d": a.d,
-                "steps": steps, "ms_per_step": wall * 1e3, "pairs_per_s": (n * (n - 1) / 2) / wall,
+                "steps": steps, "ms_per_step": wall * 1e3, "pairs_per_s": (n * (n - 1) / 2) / wall, "parity": parity,
                 "kernel": ctx.last_kernel_name(), "kernel_ms": kern_s * 1e3, "comparisons_per_s": comparisons / kern_s,
                 "frac": (insts * 64 / kern_s / 1e9 / PEAK_INT32_GOPS) if insts else None, "pmc_source": src,
                 "issue_cycles_over_simd_cycles": (issue_model(name) or {}).get("issue_cycles_over_simd_cycles")}
@@ -321,9 +410,11 @@ def parse_args(argv=None):
     ap.add_argument("-k", type=int, default=None)
     ap.add_argument("-d", type=int, default=None)
     ap.add_argument("--kernel", default="auto", choices=["auto", "direct", "bitslice"])
-    ap.add_argument("--assembly", default="torch", choices=["torch", "cabi"],
-                    help="N > 1: torch = one process per GPU, torch.distributed all-gather (default); "
-                         "cabi = one process, gkmhip_gram_allgather (one host thread per device)")
+    ap.add_argument("--assembly", default="auto", choices=["auto", "torch", "cabi"],
+                    help="N > 1: auto (default) = both, each in fresh processes with a timeout: the product's one-process "
+                         "entry gkmhip_gram_allgather as the line's numbers, torch.distributed as also.torch_dist (and as "
+                         "the fallback); cabi = one process, gkmhip_gram_allgather (one host thread per device) alone; "
+                         "torch = one process per GPU, torch.distributed all-gather alone")
     ap.add_argument("--cpu-sample", type=int, default=None,
                     help="pos (=neg) sequences of the CPU baseline sample; default: the WHOLE workload for the headline "
                          "(c2: 5 000 + 5 000, ~90 s on 16 cores), 2 000 + 2 000 otherwise")
@@ -347,7 +438,7 @@ def parse_args(argv=None):
     return args
 
 
-def launch_ranks(args, argv, cmd=None, timeout=None):
+def launch_ranks(args, argv, cmd=None, timeout=None, capture=None):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes (this
     process has not imported torch nor touched the GPU, and it never replaces itself), relay rank 0's
     stdout, fail if any rank fails.  All children are polled: the first one that exits non-zero ends the
@@ -405,23 +496,176 @@ def launch_ranks(args, argv, cmd=None, timeout=None):
     for t in threads:
         t.join(timeout=5)
     codes = [p.returncode for p in procs]
+    # rank 0's line is relayed even when a rank failed: a line whose parity check failed says so itself (exit code 3)
+    if capture is not None:      # (run_auto merges rank 0's line with the other assembly's)
+        capture.append(out0[0].decode() if out0 else "")
+    else:
+        sys.stdout.write(out0[0].decode() if out0 else "")
+        sys.stdout.flush()
     if why:
         sys.stderr.write("bench.py: %s; the other ranks were stopped (exit codes %s)\n" % (why, codes))
-        return 1
-    sys.stdout.write(out0[0].decode() if out0 else "")
-    sys.stdout.flush()
+        return codes[0] if codes and codes[0] == 3 else 1
     return max(abs(c) for c in codes)
+
+
+def _strip_flag(argv, flag, has_value=True):
+    out, skip = [], 0
+    for x in argv:
+        if skip:
+            skip -= 1
+            continue
+        if x == flag:
+            skip = 1 if has_value else 0
+            continue
+        if has_value and x.startswith(flag + "="):
+            continue
+        out.append(x)
+    return out
+
+
+def _last_json_line(text):
+    for ln in reversed((text or "").strip().splitlines()):
+        ln = ln.strip()
+        if ln.startswith("{") and ln.endswith("}"):
+            try:
+                return json.loads(ln)
+            except ValueError:
+                continue
+    return None
+
+
+def run_cabi_child(args, argv):
+    """The product's one-process multi-GPU entry (gkmhip_gram_allgather) in a FRESH child process with a timeout of its
+    own: this process has not touched a GPU and does not replace itself.  -> (line dict or None, error string or None).
+    GKM_BENCH_CABI_TIMEOUT (seconds, default 300) bounds it; the child is ended by its exact PID."""
+    timeout = float(os.environ.get("GKM_BENCH_CABI_TIMEOUT", "300"))
+    cmd = [sys.executable, os.path.abspath(__file__)] + _strip_flag(argv, "--assembly") + ["--assembly", "cabi"]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                        "MASTER_PORT") and not k.startswith("TORCHELASTIC_")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    t0 = time.time()
+    try:
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    except OSError as e:
+        return None, "cannot start the cabi child: %s" % e
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        p.kill()
+        out, err = p.communicate()
+        sys.stderr.write("[cabi] killed after %.0f s\n%s" % (timeout, err.decode(errors="replace")[-2000:]))
+        return None, "gkmhip_gram_allgather child gave no result within %.0f s and was killed" % timeout
+    tail = err.decode(errors="replace")
+    for ln in tail.splitlines()[-40:]:
+        sys.stderr.write("[cabi] %s\n" % ln)
+    line = _last_json_line(out.decode(errors="replace"))
+    if p.returncode != 0 or line is None:
+        last = [x for x in tail.strip().splitlines() if x.strip()][-1:] or ["no output"]
+        why = "parity check failed in the child" if (line or {}).get("parity_failed") else last[0][-300:]
+        return line if (line or {}).get("parity_failed") else None, \
+            "gkmhip_gram_allgather child exited with code %s after %.0f s: %s" % (p.returncode, time.time() - t0, why)
+    return line, None
+
+
+def brief_line(line):
+    """What `also.torch_dist` (or `also.cabi`) keeps of a whole line."""
+    if not line:
+        return None
+    rf = line.get("roofline") or {}
+    return {"value": line.get("value"), "unit": line.get("unit"), "ms_per_step": line.get("ms_per_step"),
+            "n_gpus": line.get("n_gpus"), "ranks": (line.get("config") or {}).get("ranks"),
+            "transport": (line.get("config") or {}).get("transport"), "chunks": (line.get("config") or {}).get("chunks"),
+            "row_sharding": (line.get("config") or {}).get("row_sharding"), "parity": line.get("parity"),
+            "frac": rf.get("frac"), "kernel_ms_per_rank": rf.get("kernel_ms_per_rank"),
+            "allgather_ms": rf.get("allgather_ms"), "assemble_ms": rf.get("assemble_ms"),
+            "allgather_bytes_per_rank": rf.get("allgather_bytes_per_rank"),
+            "allgather_GBps_per_rank": rf.get("allgather_GBps_per_rank")}
+
+
+def merge_assemblies(cabi_line, cabi_err, torch_line, torch_err):
+    """-> (the line to print, exit code).  Primary = the product's own entry; a failed / timed-out / parity-failing
+    primary is reported and the torch.distributed numbers take its place instead of the run being lost."""
+    cabi_ok = cabi_line is not None and not cabi_err and not cabi_line.get("parity_failed")
+    torch_ok = torch_line is not None and not torch_line.get("parity_failed")
+    if cabi_ok:
+        out = cabi_line
+        out["assembly"] = "cabi: gkmhip_gram_allgather (one process, one host thread per device)"
+        out.setdefault("also", {})["torch_dist"] = brief_line(torch_line) if torch_line else {"error": torch_err or "no line"}
+        return out, 0
+    if torch_line is not None:
+        out = torch_line
+        out["assembly"] = "torch: one process per GPU, torch.distributed all_gather_into_tensor (FALLBACK)"
+        out["cabi_error"] = cabi_err or "parity check failed on the gkmhip_gram_allgather matrix"
+        if cabi_line:
+            out.setdefault("also", {})["cabi"] = brief_line(cabi_line)
+        return out, (0 if torch_ok else 3)
+    sys.stderr.write("bench.py: both assemblies failed: cabi: %s; torch: %s\n" % (cabi_err, torch_err))
+    return None, 1
+
+
+def run_auto(args, argv):
+    """N > 1, --assembly auto: the product's one-process entry first (child of rank 0, while no rank has touched a
+    GPU), then the torch.distributed ranks; one merged line."""
+    torch_argv = _strip_flag(argv, "--assembly") + ["--assembly", "torch"]
+    targs = parse_args(torch_argv)
+    if "WORLD_SIZE" not in os.environ:
+        # no launcher: this process orchestrates and never touches a GPU
+        cabi_line, cabi_err = run_cabi_child(args, argv)
+        captured = []
+        rc = launch_ranks(targs, torch_argv, capture=captured)
+        torch_line = _last_json_line(captured[0]) if captured else None
+        torch_err = None if torch_line else "the torch.distributed ranks failed (exit code %d)" % rc
+        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, torch_err)
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return code
+    # under torch.distributed.run: rank 0 runs the child first; the other ranks wait for its verdict in a file
+    # (one node, by contract) before anybody imports torch or touches a GPU
+    rank = int(os.environ.get("RANK", "0"))
+    sync = os.path.join(tempfile.gettempdir(), "gkm_bench_cabi_%d_%s.json" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    wait_s = float(os.environ.get("GKM_BENCH_CABI_TIMEOUT", "300")) + 60.0
+    cabi_line = cabi_err = None
+    if rank == 0:
+        try:
+            if os.path.exists(sync):
+                os.unlink(sync)
+            cabi_line, cabi_err = run_cabi_child(args, argv)
+        finally:
+            with open(sync + ".tmp", "w") as f:
+                json.dump({"line": cabi_line, "error": cabi_err}, f)
+            os.replace(sync + ".tmp", sync)
+    else:
+        t_end = time.time() + wait_s
+        while not os.path.exists(sync) and time.time() < t_end:
+            time.sleep(0.2)
+    holder = []
+    rc = run_rank(targs, emit=holder.append)
+    if rank == 0:
+        try:
+            os.unlink(sync)
+        except OSError:
+            pass
+        torch_line = holder[0] if holder else None
+        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, None if torch_line else "rank 0 produced no line")
+        if out is not None:
+            print(json.dumps(out), flush=True)
+        return code
+    return rc
 
 
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
+    if args.gpus > 1 and args.assembly == "auto":
+        return run_auto(args, argv)
     if args.gpus > 1 and args.assembly == "torch" and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args, argv)
     return run_rank(args)
 
 
-def run_rank(args):
+def run_rank(args, emit=None):
+    """One rank (or the one process of --assembly cabi).  emit: receives rank 0's line instead of stdout."""
     # stdout carries exactly one JSON line.  Libraries write there too (RCCL prints its version
     # banner on file descriptor 1 when stderr is not a file), so descriptor 1 is pointed at stderr
     # for the duration of the run and the line goes to a private copy of the real stdout.
@@ -435,6 +679,8 @@ def run_rank(args):
     from gkmqc_amd import device, sharding
 
     cabi = args.assembly == "cabi" and args.gpus > 1
+    if cabi and os.environ.get("GKM_BENCH_CABI_FAIL") == "1":   # tests: the fallback of --assembly auto
+        raise SystemExit("injected failure of the cabi child (GKM_BENCH_CABI_FAIL)")
     world = 1 if cabi else int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0")) if not cabi else 0
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not cabi else 0
@@ -493,7 +739,9 @@ def run_rank(args):
         handles = (ctypes.c_void_p * len(ctxs))(*[c.handle for c in ctxs])
         outs = (ctypes.c_void_p * len(ctxs))(*[K.data_ptr() for K in Ks])
         lib = device.load()
-        chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4")))
+        # chunks per rank: GKM_BENCH_CHUNKS, else what the library chooses from (n, ranks) (gkm_shard.h auto_chunks)
+        chunks = max(1, int(os.environ["GKM_BENCH_CHUNKS"])) if os.environ.get("GKM_BENCH_CHUNKS") else \
+            sharding.auto_chunks(n, args.gpus)
         ctx, full = ctxs[0], Ks[0]
 
         def step():
@@ -507,17 +755,26 @@ def run_rank(args):
 
         # Row sharding: folded row blocks per rank; with more than one rank the rank's rows are cut
         # into interleaved chunks so that the RCCL all-gather of one chunk overlaps the kernel of the next.
-        chunks = max(1, int(os.environ.get("GKM_BENCH_CHUNKS", "4"))) if dist_on else 1
-        parts, pc = sharding.chunked_layout(n, world, rank, chunks)
+        chunks = 1 if not dist_on else max(1, int(os.environ["GKM_BENCH_CHUNKS"])) if os.environ.get("GKM_BENCH_CHUNKS") \
+            else sharding.auto_chunks(n, world)
+        parts, _ = sharding.chunked_layout(n, world, rank, chunks)
         full = torch.zeros((n, n), dtype=torch.float64, device=dev)
         sq = torch.zeros(n, dtype=torch.float64, device=dev)
         if dist_on:
-            slab = torch.zeros((chunks, pc, n), dtype=torch.float64, device=dev)
-            gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64, device=dev)
-            slot_of_row = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks)).to(dev)
+            # PACKED slabs (gkmqc_amd/sharding.py): row a of a chunk = a + 1 doubles, rows back to back, every chunk
+            # padded to the largest one over all ranks -- half the bytes of full-width rows
+            pe = sharding.packed_chunk_elems(n, world, chunks)
+            row_off = [sharding.packed_row_offsets(parts[c]) for c in range(chunks)]
+            slab = torch.zeros((chunks, pe), dtype=torch.float64, device=dev)
+            gathered = torch.zeros((chunks, world * pe), dtype=torch.float64, device=dev)
+            offset_of_row = torch.from_numpy(sharding.packed_gather_offsets(n, world, chunks)).to(dev)
 
         def compute(c, out_ptr, local, on=None):
-            if len(parts[c]):
+            if not len(parts[c]):
+                return
+            if dist_on:
+                ctx.gram_rows_packed(parts[c], out_ptr, row_off[c], stream if on is None else on)
+            else:
                 ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream if on is None else on)
 
         # Two side streams, chunks alternate between them: the kernel of chunk c+1 fills the CUs that the
@@ -564,8 +821,8 @@ def run_rank(args):
             if probe is not None:
                 probe["as0"] = torch.cuda.Event(enable_timing=True)
                 probe["as0"].record(main_s)
-            # un-permutation + normalisation in one pass over the gathered slabs
-            ctx.assemble_normalize(gathered.data_ptr(), n, slot_of_row.data_ptr(), full.data_ptr(), n, sq.data_ptr(),
+            # un-permutation + normalisation in one pass over the gathered (packed: lds = 1, element offsets) slabs
+            ctx.assemble_normalize(gathered.data_ptr(), 1, offset_of_row.data_ptr(), full.data_ptr(), n, sq.data_ptr(),
                                    False, stream)
             if probe is not None:
                 probe["as1"] = torch.cuda.Event(enable_timing=True)
@@ -591,6 +848,17 @@ def run_rank(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # PARITY GATE: the matrix the last timed step left behind -- every device's copy (cabi), this rank's copy (torch)
+    if cabi:
+        parity_mine = [parity_of_device_matrix(args, K) for K in Ks]
+    else:
+        parity_mine = [parity_of_device_matrix(args, full)]
+    if dist_on:
+        gathered_par = [None] * world
+        dist.all_gather_object(gathered_par, parity_mine[0])
+        parity_mine = gathered_par
+    parity = merge_parity(parity_mine)
 
     # dominant kernel: extra launches bracketed by HIP events on the launch stream (recorded inside
     # gkmhip_gram_rows), outside the wall-clock region
@@ -685,6 +953,13 @@ def run_rank(args):
                    "chunks": chunks,
                    "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("GKM_")}},
     }
+    # the parity gate: a matrix that is not the reference's, on any copy, sets the number aside
+    out["parity"] = parity
+    parity_failed = parity is not None and parity.get("ok") is False
+    if parity_failed:
+        out["parity_failed"] = True
+        out["value_set_aside"] = out["value"]
+        out["value"] = None
     if rank == 0:
         kern_s = kern_ms * 1e-3
         algorithmic = comparisons * OPS_PER_COMPARISON / kern_s / 1e9
@@ -698,7 +973,11 @@ def run_rank(args):
             executed = (insts * 64 / kern_s / 1e9) if insts else None
             ipc = (insts * 64 / comparisons) if insts else None
         else:
-            multi = multi_gpu_roofline(insts, per_rank, sec_per_step, n_gpus)
+            multi = multi_gpu_roofline(
+                insts, per_rank, sec_per_step, n_gpus,
+                bytes_per_rank=(device.load().gkmhip_allgather_bytes_per_rank() if cabi else
+                                sharding.allgather_bytes_per_rank(n, n_gpus, chunks)),
+                bytes_full_width=sharding.allgather_bytes_per_rank(n, n_gpus, chunks, packed=False))
             executed, ipc, traffic = multi["achieved"], multi["executed_insts_per_comparison"], None
         peak_meas, peak_src = measured_valu_peak()
         out["roofline"] = {
@@ -730,7 +1009,9 @@ def run_rank(args):
             rf["note"] += (" N > 1: achieved = the one-GPU launch's executed lane-ops / the max-over-ranks step time (kernels, "
                            "collectives, assembly), frac = that / (N x peak); kernel_ms, comparisons_per_launch and "
                            "comparisons_per_s are rank 0's own kernel; allgather_ms = sum over the %d chunks of the "
-                           "collective's time on its stream (HIP events), which overlaps the next chunk's kernel." % chunks)
+                           "collective's time on its stream (HIP events), which overlaps the next chunk's kernel; "
+                           "allgather_bytes_per_rank = what every rank receives from its peers per matrix (packed row "
+                           "slabs, row a = a + 1 doubles)." % chunks)
             if cabi:
                 rf["allgather_hipmalloc_calls_in_timed_region"] = allocs_timed
         # the side measurements must never cost the line itself: a failure is reported in their place
@@ -756,7 +1037,7 @@ def run_rank(args):
             try:
                 out["cpu_baseline"] = cpu_baseline(args)
                 cb = out["cpu_baseline"]
-                if cb.get("headline_workload") and cb.get("value"):
+                if cb.get("headline_workload") and cb.get("value") and out["value"]:
                     # BASELINE.md holds no published number for this metric (the reference ships none); the one
                     # baseline there is: its own CPU path on this box's host cores, same files, same N
                     out["vs_baseline"] = out["value"] / cb["value"]
@@ -765,7 +1046,10 @@ def run_rank(args):
                                              % (cb["kind"], cb["cores"]))
             except Exception as e:   # noqa: BLE001
                 out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(out), file=real_stdout, flush=True)
+        if emit is not None:
+            emit(out)
+        else:
+            print(json.dumps(out), file=real_stdout, flush=True)
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
@@ -774,7 +1058,7 @@ def run_rank(args):
             c.close()
     else:
         ctx.close()
-    return 0
+    return 3 if parity_failed else 0
 
 
 if __name__ == "__main__":

@@ -238,3 +238,16 @@ extern "C" void shardprobe_gather_index(int n, int world, int chunks, int64_t *s
     const std::vector<int64_t> s = gkmshard::chunked_gather_index(n, world, chunks);
     for (int i = 0; i < n; i++) slot_out[i] = s[(size_t)i];
 }
+
+extern "C" long long shardprobe_packed_chunk_elems(int n, int world, int chunks)
+{
+    return (long long)gkmshard::packed_chunk_elems(n, world, chunks);
+}
+
+extern "C" void shardprobe_packed_gather_offsets(int n, int world, int chunks, int64_t *off_out)
+{
+    const std::vector<int64_t> s = gkmshard::packed_gather_offsets(n, world, chunks);
+    for (int i = 0; i < n; i++) off_out[i] = s[(size_t)i];
+}
+
+extern "C" int shardprobe_auto_chunks(int n, int world) { return gkmshard::auto_chunks(n, world); }

@@ -220,12 +220,13 @@ struct gkmhip_ctx {
      * two streams alternates the slot, so a launch never rewrites what the previous one still reads */
     struct Scratch {
         DevBuf<int> rows;
+        DevBuf<int64_t> rowoff;    /* packed row offsets (general kernel only; the bit-sliced one has them in `tables`) */
         DevBuf<char> tables;       /* all per-launch tables of the bit-sliced kernel, one upload */
         DevBuf<uint32_t> rowplanes, rowpk;
         DevBuf<double> S;          /* tile-transposed raw values (k_gram_bitslice -> k_untile) */
         void release()
         {
-            rows.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
+            rows.release(); rowoff.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
         }
     } scratch[2];
     int sel = 0;
@@ -398,7 +399,15 @@ struct GramOut {
     int local_rows;
     int write_all;  /* 0: only j <= a (lower triangle + diagonal); 1: every column visited */
     double *diag;   /* if set: diag[a] = G(a,a) */
+    /* if set (packed row slabs, gkm_shard.h): local row r starts at G + row_off[r] instead of G + r * ld.
+     * gram_launch() receives the HOST array and replaces it by its device copy. */
+    const int64_t *row_off;
 };
+
+__device__ __forceinline__ double *gram_cell(const GramOut &out, int64_t r, int j)
+{
+    return out.G + (out.row_off ? out.row_off[r] : r * out.ld) + j;
+}
 
 /* which columns a tile of rows visits */
 enum { COLS_TRIANGLE = 0, COLS_FULL = 1, COLS_DIAGONAL = 2 };
@@ -508,7 +517,7 @@ constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
  * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
  * control flow besides the push.
  */
-template <int W, int L, int D, int PK, int VARIANT = 0>
+template <int W, int L, int D, int PK>
 __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
@@ -519,14 +528,10 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
     constexpr bool PACKED = PK == 1 || PK == 2;
     constexpr bool BPERM = PK == 3;
-    /* VARIANT (timing experiments only, -DGKM_TIMING_VARIANTS builds, selected by GKM_VARIANT; results are
-     * wrong for != 0): 1 = hits only counted, no queue; 2 = queue filled but never consumed; 4 = SB words
-     * fetched with vector loads into VGPRs instead of scalar loads into SGPRs; 16 = trips without the table
-     * reads; 32 = records pushed, trips skipped; 64 = multi-hit records dropped after their first hit;
-     * 128 = trips without the LDS accumulate; 256 = the resolved hit's whole word cleared by a plain store instead of the LDS xor;
-     * 512 = the row lane's packed words read from (arbitrary) LDS instead of global memory: 76.4 vs 77.6 ms on config 2,
-     * 434 vs 454 ms on gkmQC's defaults -- what an LDS-resident copy of the tile's 5.4 KB could gain at best, before paying for it;
-     * 2048 = column words made up by scalar arithmetic instead of scalar loads (what hiding the scalar-load latency could gain) */
+    /* (The ablation builds of rounds 1-3 -- parts of this kernel skipped to time the rest, results wrong -- lived
+     * here as a fifth template parameter; they are gone from the source since round 4.  tools/variants.sh rebuilds
+     * them from revision a4bed73, profiles/r2_ablation_timings.txt and r2_pmc_ablation_builds*.txt hold what they
+     * measured.) */
     using namespace gkmbs;
     /* LDS per wave: 3 KB hit list + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
      * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
@@ -644,7 +649,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * v_bitop3_b32, the weight table's LDS offset as the third operand of the v_sad_u32 that forms the index.
          * Same arithmetic as resolve_hit_packed (gkm_bitslice.h), which the CPU tests run against the oracle. */
         auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
-            if (VARIANT & 16) { atomicAdd(&accl[rec_lane(ms)], ms | (bit << 24)); return; } /* timing: no table reads */
             const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
             const int k = PACKED ? piece_of_bitrow(*(const uint32_t *)((const char *)lmask + (PACKED ? (lane128 >> 5) : 0u)), (int)bit) : 0;
             uint32_t slot4, c0b; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
@@ -669,9 +673,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
             if ((int)q < nB) {
                 /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
-                const uint32_t *rw = (VARIANT & 512) /* timing: the row words from (arbitrary) LDS instead of global memory */
-                    ? (const uint32_t *)((const char *)s_list + ((lane128 + ((i0 >> 2) & ~3u)) & 0x7F8u))
-                    : (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+                const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
                 const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, (ms >> 2) & 4u));
                 const uint8_t *wdb = (const uint8_t *)s_dyn;
                 const uint32_t wa = wdb[__usad(c0b, i0 | 2048u, wbase)];
@@ -680,7 +682,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
                 const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
                 const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
-                if (VARIANT & 128) { asm volatile("" ::"v"(m), "v"(wa), "v"(wb), "v"(slot4)); return; } /* timing: no accumulate */
                 if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 */
                     atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
             }
@@ -721,8 +722,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
             if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
             s_n -= c;
-            const unsigned long long more = (VARIANT & 64) ? 0ull /* timing: multi-hit records dropped */
-                                                           : __ballot(total > 1u);
+            const unsigned long long more = __ballot(total > 1u);
             if (more) {
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
                                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
@@ -731,8 +731,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
 #pragma unroll
                     for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
                     *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
-                    if (VARIANT & 256) *(volatile uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)) = 0u; /* timing: plain store, the word is dropped */
-                    else atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
+                    atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
                 }
                 s_n += (int)__popcll(more);
             }
@@ -746,7 +745,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * hits left is a popcount sum, and a record that goes back to the list is copied unchanged and
          * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
         auto trips = [&](bool final) {
-            if (VARIANT & 32) s_n = 0; /* timing: list filled, never resolved */
             while (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
             if (final)
                 while (s_n > 0) {
@@ -758,9 +756,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         for (int strand = 0; strand < 2; strand++) {
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
-            typedef typename std::conditional<(VARIANT & 4) != 0, const uint32_t *, sgpr_words>::type sb_ptr;
-            const sb_ptr sbh = (sb_ptr)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
-            const sb_ptr sbl = sbh + A.xw;
+            const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
+            const sgpr_words sbl = sbh + A.xw;
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
                 /* (copying the words to VGPRs once instead of using them as SGPR operands was measured
                  * slower: 119-129 ms against 111.6 ms on config 2; requesting the next block's words one
@@ -770,11 +767,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
 #pragma unroll
                 for (int i = 0; i < BS_DU + W - 1; i++) {
-                    if (VARIANT & 2048) { /* timing: no scalar loads, the column words are made up (SALU) */
-                        bh[i] = (uint32_t)(d0 + i + j) * 2654435761u;
-                        bl[i] = (uint32_t)(d0 + i + strand) * 2246822519u + (uint32_t)j;
-                        continue;
-                    }
                     bh[i] = sbh[d0 + i];
                     bl[i] = sbl[d0 + i];
                 }
@@ -786,11 +778,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                         const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand, ceven);
 #pragma unroll
                         for (int w0 = 0; w0 < W; w0 += BS_GRP) {
-                            if ((VARIANT & 3) == 1) {
-#pragma unroll
-                                for (int g = 0; g < BS_GRP; g++) accl[lane] += __popc(hit[w0 + g]);
-                                continue;
-                            }
                             /* wave-level compaction at the source, once per group of BS_GRP words: the
                              * lanes with a hit in the group append (words, origin) to the list at tail
                              * + their rank among the hit lanes (ballot + mbcnt); EXEC-masked stores, no
@@ -809,8 +796,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                                 *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;
                             }
                             s_n += (int)__popcll(mask);
-                            if ((VARIANT & 3) == 2) { if (s_n >= BS_TRIP) s_n = 0; }
-                            else if (s_n >= BS_TRIP) trips(false);
+                            if (s_n >= BS_TRIP) trips(false);
                         }
                     }
                 }
@@ -867,7 +853,7 @@ __global__ __launch_bounds__(256) void k_untile(const double *__restrict__ S, co
         const int j = jb + tx;
         if (j >= cend || (j > row && !out.write_all)) continue;
         const int64_t r = out.local_rows ? tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
-        out.G[r * out.ld + j] = buf[tx][rl];
+        *gram_cell(out, r, j) = buf[tx][rl];
     }
 }
 
@@ -935,7 +921,7 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
             for (int m = 0; m <= d; m++) g += A.c[m] * (double)(int32_t)acc[m][lane];
             const int64_t r = A.out.local_rows ? ridx : a;
             if (A.out.diag && j == a) A.out.diag[a] = g;
-            if (A.out.G) A.out.G[r * A.out.ld + j] = g;
+            if (A.out.G) *gram_cell(A.out, r, j) = g;
             if (A.out.P)
                 for (int m = 0; m <= d; m++) A.out.P[(r * A.out.ldp + j) * (d + 1) + m] = (int32_t)acc[m][lane];
         }
@@ -1087,22 +1073,6 @@ static bs_kernel_t pick_bitslice(int L, int d)
 {
 #define GKM_BS(LL, DD) \
     if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
-#ifdef GKM_TIMING_VARIANTS
-    /* Ablation builds only (tools/variants.sh compiles them into build_variants/ with
-     * -DGKM_TIMING_VARIANTS): VARIANT != 0 skips parts of the kernel, the results are WRONG.  The
-     * product library is built without the macro: no such instantiation, no environment switch
-     * (tests/test_host_logic.py::test_no_timing_variants_in_the_product). */
-    {
-        const char *v = getenv("GKM_VARIANT");
-        const int vi = v ? atoi(v) : 0;
-#define GKM_VAR(LL, DD, VV) \
-        if (L == LL && d == DD && vi == VV) return k_gram_bitslice<W, LL, DD, PACKED, VV>;
-#define GKM_VARS(LL, DD) GKM_VAR(LL, DD, 1) GKM_VAR(LL, DD, 2) GKM_VAR(LL, DD, 16) GKM_VAR(LL, DD, 32) GKM_VAR(LL, DD, 64) GKM_VAR(LL, DD, 128) GKM_VAR(LL, DD, 256) GKM_VAR(LL, DD, 512) GKM_VAR(LL, DD, 2048) GKM_VAR(LL, DD, 2080)
-        GKM_VARS(11, 3) GKM_VARS(10, 3)
-#undef GKM_VARS
-#undef GKM_VAR
-    }
-#endif
     /* every (L, d) with 3 <= L <= 12, d <= min(4, L - 1) (what bin/gkmqc.py:185 can ask for), plus the d > 4 pairs
      * where this kernel still beats k_gram_direct: a hit costs a whole lane of a trip (~64 lane-instructions), a
      * comparison 0.45, the general kernel ~5.5 per comparison whatever the hit rate -- break-even at ~8 % of
@@ -1233,6 +1203,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t o_cbeg = put(cbeg.data(), (size_t)ntiles * sizeof(int));
         const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
         const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
+        const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
@@ -1275,6 +1246,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
+        if (out.row_off) A.out.row_off = (const int64_t *)(tb + o_roff);
         A.ntiles = ntiles;
         A.S = out.G ? scr.S.p : nullptr;
         A.tile_soff = (const int64_t *)(tb + o_soff);
@@ -1291,10 +1263,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / 64)));
             if (slots != 64)
                 hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
-                                   A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, out);
+                                   A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, A.out);
             else
                 hipLaunchKernelGGL(k_untile<64>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
-                                   A.tile_nrows, A.tile_row, A.tile_out, out);
+                                   A.tile_nrows, A.tile_row, A.tile_out, A.out);
             HIPCHK(hipGetLastError());
         }
         ctx->last_kernel = bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
@@ -1302,6 +1274,12 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
         HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (out.row_off) {
+            if (ctx->scratch[ctx->sel].rowoff.ensure((size_t)nrows)) return 4;
+            HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rowoff.p, out.row_off, (size_t)nrows * sizeof(int64_t),
+                                  hipMemcpyHostToDevice, stream));
+            out.row_off = ctx->scratch[ctx->sel].rowoff.p;
+        }
         HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
         DirectArgs A;
         A.rows = ctx->scratch[ctx->sel].rows.p; A.nrows = nrows;
@@ -1333,7 +1311,20 @@ extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int
     if (!G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows: bad arguments", 2);
     if (ld <= rows[nrows - 1]) return set_err_msg("leading dimension too small", 2);
     GramOut out;
-    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows; out.write_all = 0; out.diag = nullptr;
+    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows; out.write_all = 0; out.diag = nullptr; out.row_off = nullptr;
+    return gram_launch(ctx, rows, nrows, COLS_TRIANGLE, out, (hipStream_t)stream_);
+}
+
+extern "C" int gkmhip_gram_rows_packed(gkmhip_ctx *ctx, const int *rows, int nrows, double *G, const int64_t *row_off,
+                                       void *stream_)
+{
+    if (!G || !rows || nrows <= 0 || !row_off) return set_err_msg("gkmhip_gram_rows_packed: bad arguments", 2);
+    for (int i = 0; i < nrows; i++) /* rows may touch (row i ends where row i + 1 starts) but never overlap */
+        if (row_off[i] < 0 || (i + 1 < nrows && row_off[i + 1] < row_off[i] + (int64_t)rows[i] + 1))
+            return set_err_msg("gkmhip_gram_rows_packed: row offsets must leave rows[i] + 1 doubles per row", 2);
+    GramOut out;
+    out.G = G; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 1; out.write_all = 0; out.diag = nullptr;
+    out.row_off = row_off;
     return gram_launch(ctx, rows, nrows, COLS_TRIANGLE, out, (hipStream_t)stream_);
 }
 
@@ -1343,7 +1334,7 @@ extern "C" int gkmhip_gram_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows
     if (!ctx || !G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows_full: bad arguments", 2);
     if (ld < ctx->n) return set_err_msg("leading dimension too small", 2);
     GramOut out;
-    out.G = G; out.ld = ld; out.P = nullptr; out.ldp = 0; out.local_rows = local_rows; out.write_all = 1; out.diag = nullptr;
+    out.G = G; out.ld = ld; out.P = nullptr; out.ldp = 0; out.local_rows = local_rows; out.write_all = 1; out.diag = nullptr; out.row_off = nullptr;
     return gram_launch(ctx, rows, nrows, COLS_FULL, out, (hipStream_t)stream_);
 }
 
@@ -1360,7 +1351,7 @@ extern "C" int gkmhip_self_norms(gkmhip_ctx *ctx, double *sqnorm, void *stream_)
     std::vector<int> all((size_t)ctx->n);
     for (int i = 0; i < ctx->n; i++) all[(size_t)i] = i;
     GramOut out;
-    out.G = nullptr; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 0; out.write_all = 0; out.diag = sqnorm;
+    out.G = nullptr; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 0; out.write_all = 0; out.diag = sqnorm; out.row_off = nullptr;
     const int rc = gram_launch(ctx, all.data(), ctx->n, COLS_DIAGONAL, out, stream);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sqrt_inplace, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, stream, sqnorm, ctx->n);
@@ -1456,7 +1447,9 @@ __global__ void k_assemble_normalize(const double *__restrict__ src, int64_t lds
 extern "C" int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds, const int64_t *slot_of_row,
                                          double *K, int64_t ld, double *sqnorm, int symmetric, void *stream_)
 {
-    if (!ctx || !slabs || !slot_of_row || !K || !sqnorm || ctx->n <= 0 || ld < ctx->n || lds < ctx->n)
+    /* lds >= n: slot_of_row[a] is the ROW of a row-major [*, lds] array that holds matrix row a;
+     * lds == 1: slot_of_row[a] is the element offset at which matrix row a starts (packed slabs, gkm_shard.h) */
+    if (!ctx || !slabs || !slot_of_row || !K || !sqnorm || ctx->n <= 0 || ld < ctx->n || (lds < ctx->n && lds != 1))
         return set_err_msg("gkmhip_assemble_normalize: bad arguments", 2);
     hipStream_t stream = (hipStream_t)stream_;
     HIPCHK(hipSetDevice(ctx->device));
@@ -1467,6 +1460,64 @@ extern "C" int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, i
                        slot_of_row, K, ld, sqnorm, ctx->rbf, ctx->gamma, symmetric);
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+/* ---- device matrix -> the caller's (pageable) host rows, shared by the drop-in call and gkmhip_copy_lower_to_rows ----
+ * A PIECE is rows [r0, r1) with columns [0, r1): it fits one pinned staging buffer.  Piece q+1 travels (hipMemcpy2DAsync
+ * on `sd`, issued by `issue`) while the host threads scatter piece q into rows[r][0..r]. */
+struct RowPiece { int r0, r1; };
+
+/* pieces of rows [r0, r1) whose staging rectangles hold at most `bytes` */
+static void cut_pieces(int r0, int r1, size_t bytes, std::vector<RowPiece> &out)
+{
+    for (int q0 = r0; q0 < r1;) {
+        int q1 = q0 + 1;
+        while (q1 < r1 && (size_t)(q1 + 1) * (size_t)(q1 + 1 - q0) * 8 <= bytes) q1++;
+        out.push_back({q0, q1});
+        q0 = q1;
+    }
+}
+
+struct StreamPair { /* destroyed on every path out of the function that owns it */
+    hipStream_t a = nullptr, b = nullptr;
+    ~StreamPair()
+    {
+        if (a) (void)hipStreamDestroy(a);
+        if (b) (void)hipStreamDestroy(b);
+    }
+};
+
+template <class Issue>
+static hipError_t ship_pieces(const std::vector<RowPiece> &pieces, double *const stage[2], hipStream_t sd, double **rows,
+                              int nthreads, Issue issue, double *t_wait, double *t_scatter)
+{
+    auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const size_t NP = pieces.size();
+    hipError_t e = NP ? issue((size_t)0) : hipSuccess;
+    for (size_t q = 0; e == hipSuccess && q < NP; q++) {
+        const double tw = now();
+        e = hipStreamSynchronize(sd); /* piece q is in stage[q & 1] */
+        if (e != hipSuccess) break;
+        if (q + 1 < NP) e = issue(q + 1);
+        const double ts = now();
+        if (t_wait) *t_wait += ts - tw;
+        const RowPiece &k = pieces[q];
+        const double *src = stage[q & 1];
+        auto work = [&](int t) {
+            for (int r = k.r0 + t; r < k.r1; r += nthreads)
+                memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));
+        };
+        if (nthreads == 1 || k.r1 - k.r0 < 64) {
+            for (int t = 0; t < nthreads; t++) work(t);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        if (t_scatter) *t_scatter += now() - ts;
+    }
+    return e;
 }
 
 /* Whole matrix into caller-owned host rows (rows[a][0..a]) as a pipeline over row blocks of
@@ -1496,8 +1547,7 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
      * cannot overlap anything, so the blocks shrink geometrically -- 1/2, 1/4, ... of the area, the last ones
      * 2-5 % -- and a block travels in as many staging-sized pieces as it needs: 6 launches instead of 13 for
      * 10 000 rows and a short tail, 87 instead of 90 ms (GKM_EQUAL_BLOCKS=1 keeps the equal blocks, for A/B runs). */
-    struct Blk { int r0, r1; };
-    std::vector<Blk> blocks, pieces;
+    std::vector<RowPiece> blocks, pieces;
     std::vector<int> block_of; /* piece -> block */
     const bool geometric = nparts == 1 && getenv("GKM_EQUAL_BLOCKS") == nullptr;
     const double total_area = (double)n * n / 2.0;
@@ -1518,13 +1568,8 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
                 r1++;
         }
         if (index++ % nparts == part) {
-            for (int q0 = r0; q0 < r1;) { /* pieces: rows [q0, q1), columns [0, q1) fit a staging buffer */
-                int q1 = q0 + 1;
-                while (q1 < r1 && (size_t)(q1 + 1) * (size_t)(q1 + 1 - q0) * 8 <= want) q1++;
-                pieces.push_back({q0, q1});
-                block_of.push_back((int)blocks.size());
-                q0 = q1;
-            }
+            cut_pieces(r0, r1, want, pieces);
+            block_of.resize(pieces.size(), (int)blocks.size());
             blocks.push_back({r0, r1});
         }
         r0 = r1;
@@ -1538,9 +1583,10 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     /* (Alternating the blocks' Gram kernels between two streams, so that block b+1 fills the CUs block b's
      * drain leaves idle, was measured: 107 instead of 89 ms for the 10 000-row call -- two tiles' worth of
      * waves on a CU evict each other's packed rows from L1, as with the column-major block order.) */
-    hipStream_t sc = nullptr, sd = nullptr;
-    HIPCHK(hipStreamCreate(&sc));
-    HIPCHK(hipStreamCreate(&sd));
+    StreamPair sp;
+    HIPCHK(hipStreamCreate(&sp.a));
+    HIPCHK(hipStreamCreate(&sp.b));
+    const hipStream_t sc = sp.a, sd = sp.b;
     std::vector<hipEvent_t> done(B, nullptr);
     int rc = 0;
     std::vector<int> idx;
@@ -1555,37 +1601,14 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     }
     const size_t NP = pieces.size();
     auto issue = [&](size_t q) -> hipError_t {
-        const Blk &k = pieces[q];
+        const RowPiece &k = pieces[q];
         hipError_t e = hipStreamWaitEvent(sd, done[(size_t)block_of[q]], 0);
         if (e != hipSuccess) return e;
         return hipMemcpy2DAsync(stage[q & 1], (size_t)k.r1 * 8, G + (size_t)k.r0 * ld, (size_t)ld * 8,
                                 (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sd);
     };
     const double t_enq = now();
-    hipError_t e = rc ? hipErrorUnknown : issue(0);
-    for (size_t b = 0; e == hipSuccess && b < NP; b++) {
-        const double tw = now();
-        e = hipStreamSynchronize(sd); /* piece b is in stage[b & 1] */
-        if (e != hipSuccess) break;
-        if (b + 1 < NP) e = issue(b + 1);
-        t_wait += now() - tw;
-        const double ts = now();
-        const Blk &k = pieces[b];
-        const double *src = stage[b & 1];
-        auto work = [&](int t) {
-            for (int r = k.r0 + t; r < k.r1; r += nthreads)
-                memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));
-        };
-        if (nthreads == 1 || k.r1 - k.r0 < 64) {
-            for (int t = 0; t < nthreads; t++) work(t);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
-            work(0);
-            for (auto &x : th) x.join();
-        }
-        t_scatter += now() - ts;
-    }
+    const hipError_t e = rc ? hipErrorUnknown : ship_pieces(pieces, stage, sd, rows, nthreads, issue, &t_wait, &t_scatter);
     (void)hipStreamSynchronize(sc);
     (void)hipStreamSynchronize(sd);
     if (trace)
@@ -1593,8 +1616,6 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
                 B, NP, t_enq - t0, t_wait, t_scatter, now() - t0);
     for (auto ev : done)
         if (ev) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(sc);
-    (void)hipStreamDestroy(sd);
     if (rc) return rc;
     if (e != hipSuccess) return set_err("gkmhip_gram_to_host_rows", e, __FILE__, __LINE__);
     return 0;
@@ -1638,8 +1659,8 @@ extern "C" int gkmhip_sync(void *stream)
     return 0;
 }
 
-/* Lower triangle of a device matrix into caller-owned host rows, through two pinned
- * staging buffers: the D2H DMA of block k+1 overlaps the host scatter of block k. */
+/* Lower triangle of a device matrix into caller-owned host rows, through the same piece pipeline as the drop-in
+ * call (cut_pieces / ship_pieces): the D2H DMA of piece q+1 overlaps the host scatter of piece q. */
 extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64_t ld, int n, double **rows,
                                          int nthreads)
 {
@@ -1648,46 +1669,18 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
     const size_t want = (size_t)64 << 20;
     double *stage[2];
     if (acquire_staging(want, stage, 0)) return 4;
-    if (nthreads < 1) nthreads = 1;
-    if (nthreads > 16) nthreads = 16;
-    hipStream_t s;
-    HIPCHK(hipStreamCreate(&s));
-    struct Blk { int r0, r1; };
-    std::vector<Blk> blocks;
-    for (int r0 = 0; r0 < n;) {
-        /* rows r0..r1-1, each copied with width r1 (elements): r1*(r1-r0)*8 <= want */
-        int r1 = r0 + 1;
-        while (r1 < n && (size_t)(r1 + 1) * (size_t)(r1 + 1 - r0) * 8 <= want) r1++;
-        blocks.push_back({r0, r1});
-        r0 = r1;
-    }
-    auto issue = [&](size_t b) -> hipError_t {
-        const Blk &k = blocks[b];
-        return hipMemcpy2DAsync(stage[b & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
-                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, s);
+    nthreads = std::min(std::max(nthreads, 1), 16);
+    StreamPair sp;
+    HIPCHK(hipStreamCreate(&sp.a));
+    std::vector<RowPiece> pieces;
+    cut_pieces(0, n, want, pieces);
+    auto issue = [&](size_t q) -> hipError_t {
+        const RowPiece &k = pieces[q];
+        return hipMemcpy2DAsync(stage[q & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
+                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sp.a);
     };
-    hipError_t e = issue(0);
-    for (size_t b = 0; e == hipSuccess && b < blocks.size(); b++) {
-        e = hipStreamSynchronize(s);
-        if (e != hipSuccess) break;
-        if (b + 1 < blocks.size()) e = issue(b + 1);
-        const Blk &k = blocks[b];
-        const double *src = stage[b & 1];
-        auto work = [&](int t) {
-            for (int r = k.r0 + t; r < k.r1; r += nthreads)
-                memcpy(rows[r], src + (size_t)(r - k.r0) * k.r1, (size_t)(r + 1) * sizeof(double));
-        };
-        if (nthreads == 1 || k.r1 - k.r0 < 64) {
-            for (int t = 0; t < nthreads; t++) work(t);
-        } else {
-            std::vector<std::thread> th;
-            for (int t = 1; t < nthreads; t++) th.emplace_back(work, t);
-            work(0);
-            for (auto &x : th) x.join();
-        }
-    }
-    (void)hipStreamSynchronize(s);
-    (void)hipStreamDestroy(s);
+    const hipError_t e = ship_pieces(pieces, stage, sp.a, rows, nthreads, issue, nullptr, nullptr);
+    (void)hipStreamSynchronize(sp.a);
     if (e != hipSuccess) return set_err("copy_lower_to_rows", e, __FILE__, __LINE__);
     return 0;
 }

@@ -14,6 +14,8 @@
  *   p2p   every rank pulls its peers' slabs with hipMemcpyPeerAsync.  Used when several contexts
  *         share a device (the one-GPU rehearsal of the N > 1 path: RCCL refuses duplicate devices)
  *         or when RCCL cannot be loaded.  GKM_ALLGATHER=rccl|p2p forces one.
+ * What travels are PACKED slabs (gkm_shard.h): row a as a + 1 doubles -- only j <= a is ever read -- n^2 / (2G)
+ * doubles per rank and matrix, half of what full-width rows cost (round 3).
  * The chunks of a rank alternate between two compute streams; the transfer of chunk c runs on a
  * third stream and overlaps the kernel of chunk c+1.  Integer profiles are placement-independent,
  * so the assembled matrix is bit-identical to the single-GPU one for any number of devices.
@@ -151,7 +153,8 @@ private:
  * ~1.7 GB and freed it again paid for that beside a ~10 ms kernel on 8 GPUs.  Keyed by (device, n, ranks, chunks);
  * rebuilt when any of them changes, freed by gkmhip_release_comms(). */
 struct RankCache {
-    int dev = -1, n = 0, G = 0, chunks = 0, pc = 0;
+    int dev = -1, n = 0, G = 0, chunks = 0;
+    int64_t pe = 0; /* doubles per (packed) chunk slab */
     double *slab = nullptr, *gathered = nullptr, *sq = nullptr;
     int64_t *d_slot = nullptr;
     hipStream_t sk[2] = {nullptr, nullptr}, sc = nullptr;
@@ -184,13 +187,13 @@ void cache_release(RankCache &R)
 }
 
 struct Call {
-    int G = 0, n = 0, chunks = 1, pc = 0, symmetric = 0;
-    int64_t ld = 0;
+    int G = 0, n = 0, chunks = 1, symmetric = 0;
+    int64_t ld = 0, pe = 0;
     bool use_rccl = false;
     gkmhip_ctx **ctxs = nullptr;
     double **K = nullptr;
     std::vector<int> devs;
-    std::vector<int64_t> slot_of_row;
+    std::vector<int64_t> row_offset; /* where matrix row a starts in the gathered slabs (gkm_shard.h) */
     std::vector<std::string> err;
     std::atomic<int> failed{0};
     std::atomic<int> stuck{0}; /* a collective was enqueued by some ranks only: do not wait for it */
@@ -201,6 +204,7 @@ struct Call {
 struct RankStats { double kernel_ms = 0, transfer_ms = 0, assemble_ms = 0, comparisons = 0; };
 std::vector<RankStats> g_stats;
 int g_stats_chunks = 0;
+long long g_bytes_per_rank = 0; /* received from the peers per matrix by every rank in the most recent call */
 
 #define MCHK(expr)                                                                              \
     do {                                                                                        \
@@ -214,16 +218,18 @@ int g_stats_chunks = 0;
 void rank_thread(Call &C, int g)
 {
     bool fail = false;
-    const int G = C.G, n = C.n, chunks = C.chunks, pc = C.pc, dev = C.devs[(size_t)g];
-    const size_t slab_elems = (size_t)pc * (size_t)n;
+    const int G = C.G, n = C.n, chunks = C.chunks, dev = C.devs[(size_t)g];
+    /* PACKED slabs: row a of a chunk is a + 1 doubles, rows back to back, every chunk padded to the largest one
+     * over all ranks (gkm_shard.h) -- n^2 / (2G) doubles per rank instead of n^2 / G */
+    const size_t slab_elems = (size_t)C.pe;
     RankCache &R = g_cache[g];
     const std::vector<std::vector<int>> parts = gkmshard::chunked_layout(n, G, g, chunks);
 
     /* ---- phase 0: buffers, streams, events (kept from the previous call of the same shape) ---- */
     MCHK(hipSetDevice(dev));
-    if (!fail && !(R.dev == dev && R.n == n && R.G == G && R.chunks == chunks && R.pc == pc)) {
+    if (!fail && !(R.dev == dev && R.n == n && R.G == G && R.chunks == chunks && R.pe == C.pe)) {
         cache_release(R);
-        R.dev = dev; R.n = n; R.G = G; R.chunks = chunks; R.pc = pc;
+        R.dev = dev; R.n = n; R.G = G; R.chunks = chunks; R.pe = C.pe;
         auto dmalloc = [&](void **p, size_t bytes) { g_allocs++; return hipMalloc(p, bytes); };
         MCHK(dmalloc((void **)&R.slab, (size_t)chunks * slab_elems * sizeof(double)));
         if (!fail) MCHK(dmalloc((void **)&R.gathered, (size_t)chunks * (size_t)G * slab_elems * sizeof(double)));
@@ -240,7 +246,7 @@ void rank_thread(Call &C, int g)
         }
         if (!fail) MCHK(hipEventCreate(&R.n0));
         if (!fail) MCHK(hipEventCreate(&R.n1));
-        if (!fail) MCHK(hipMemcpy(R.d_slot, C.slot_of_row.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (!fail) MCHK(hipMemcpy(R.d_slot, C.row_offset.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
         if (fail) { /* half-built: nothing of it may be taken for a cache hit later */
             const std::string keep = C.err[(size_t)g];
             cache_release(R);
@@ -261,8 +267,9 @@ void rank_thread(Call &C, int g)
             const std::vector<int> &rows = parts[(size_t)c];
             MCHK(hipEventRecord(R.k0[(size_t)c], st));
             if (!rows.empty()) {
+                const std::vector<int64_t> roff = gkmshard::packed_row_offsets(rows);
                 int rc = gkmhip_set_scratch_slot(C.ctxs[g], c & 1);
-                if (!rc) rc = gkmhip_gram_rows(C.ctxs[g], rows.data(), (int)rows.size(), 1, my_slab, n, nullptr, 0, st);
+                if (!rc) rc = gkmhip_gram_rows_packed(C.ctxs[g], rows.data(), (int)rows.size(), my_slab, roff.data(), st);
                 if (rc && !fail) { fail = true; C.err[(size_t)g] = gkmhip_last_error(); }
                 if (!rc) st_out.comparisons += gkmhip_last_comparisons(C.ctxs[g]);
             }
@@ -290,9 +297,11 @@ void rank_thread(Call &C, int g)
         } else {
             /* every rank has RECORDED ready[.][c]: an unrecorded event would not be waited for */
             if (!C.bar->wait(C.failed.load() != 0)) {
+                /* first every peer's slab, THEN the start event: transfer_ms brackets the copies only, as the RCCL
+                 * branch's brackets the collective only (not the wait for the slowest peer's kernel) */
+                for (int r = 0; r < G && !fail; r++) MCHK(hipStreamWaitEvent(sc, g_cache[r].ready[(size_t)c], 0));
                 MCHK(hipEventRecord(R.a0[(size_t)c], sc));
                 for (int r = 0; r < G && !fail; r++) {
-                    MCHK(hipStreamWaitEvent(sc, g_cache[r].ready[(size_t)c], 0));
                     MCHK(hipMemcpyPeerAsync(R.gathered + ((size_t)c * (size_t)G + (size_t)r) * slab_elems, dev,
                                             g_cache[r].slab + (size_t)c * slab_elems, C.devs[(size_t)r],
                                             slab_elems * sizeof(double), sc));
@@ -308,7 +317,7 @@ void rank_thread(Call &C, int g)
     bool assembled = false;
     if (!C.failed.load()) {
         MCHK(hipEventRecord(R.n0, sc));
-        const int rc = gkmhip_assemble_normalize(C.ctxs[g], R.gathered, n, R.d_slot, C.K[g], C.ld, R.sq, C.symmetric, sc);
+        const int rc = gkmhip_assemble_normalize(C.ctxs[g], R.gathered, 1, R.d_slot, C.K[g], C.ld, R.sq, C.symmetric, sc);
         if (rc && !fail) { fail = true; C.err[(size_t)g] = gkmhip_last_error(); }
         MCHK(hipEventRecord(R.n1, sc));
         assembled = !fail;
@@ -347,6 +356,7 @@ extern "C" void gkmhip_release_comms(void)
 }
 
 extern "C" long gkmhip_allgather_alloc_count(void) { return g_allocs.load(); }
+extern "C" long long gkmhip_allgather_bytes_per_rank(void) { return g_bytes_per_rank; }
 
 /* out[0] = ranks, out[1] = chunks, out[2] = transport (0 none, 1 p2p, 2 rccl), then per rank
  * {kernel ms (sum over chunks), transfer ms (sum over chunks), assemble ms, l-mer comparisons} */
@@ -387,9 +397,10 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
         for (int h = 0; h < g; h++) distinct = distinct && C.devs[(size_t)h] != C.devs[(size_t)g];
     }
     if (C.n <= 0 || ld < C.n) { return fail_with("gkmhip_gram_allgather: no sequences uploaded or leading dimension too small", 2); }
-    C.chunks = nctx == 1 ? 1 : (chunks > 0 ? chunks : 4);
-    C.pc = gkmshard::chunk_rows(C.n, nctx, C.chunks);
-    C.slot_of_row = gkmshard::chunked_gather_index(C.n, nctx, C.chunks);
+    C.chunks = nctx == 1 ? 1 : (chunks > 0 ? chunks : gkmshard::auto_chunks(C.n, nctx));
+    C.pe = gkmshard::packed_chunk_elems(C.n, nctx, C.chunks);
+    C.row_offset = gkmshard::packed_gather_offsets(C.n, nctx, C.chunks);
+    g_bytes_per_rank = (long long)C.chunks * (nctx - 1) * (long long)C.pe * 8;
 
     const char *force = getenv("GKM_ALLGATHER");
     const bool want_rccl = force ? !strcmp(force, "rccl") : (nctx > 1 && distinct);

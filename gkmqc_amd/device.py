@@ -101,6 +101,10 @@ def load():
     L.gkmhip_set_sequences.argtypes = (vp, i32, vp, vp, vp, i32, vp)
     L.gkmhip_gram_rows.restype = i32
     L.gkmhip_gram_rows.argtypes = (vp, vp, i32, i32, vp, i64, vp, i64, vp)
+    if hasattr(L, "gkmhip_gram_rows_packed"):   # (older builds loaded through GKM_LIB_PATH for A/B timing lack it)
+        L.gkmhip_gram_rows_packed.restype = i32
+        L.gkmhip_gram_rows_packed.argtypes = (vp, vp, i32, vp, vp, vp)
+        L.gkmhip_allgather_bytes_per_rank.restype = ctypes.c_longlong
     L.gkmhip_gram_rows_full.restype = i32
     L.gkmhip_gram_rows_full.argtypes = (vp, vp, i32, i32, vp, i64, vp)
     L.gkmhip_self_norms.restype = i32
@@ -300,6 +304,13 @@ class GramContext:
         self._chk(self.lib.gkmhip_gram_rows(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr, ld,
                                             P_ptr, ldp, stream), "gkmhip_gram_rows")
 
+    def gram_rows_packed(self, rows, G_ptr, row_off, stream=0):
+        """Row rows[i] -> G_ptr + row_off[i] doubles, columns 0..rows[i] only (packed slabs, sharding.py)."""
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        row_off = np.ascontiguousarray(row_off[:len(rows)], dtype=np.int64)
+        self._chk(self.lib.gkmhip_gram_rows_packed(self.handle, rows.ctypes.data, len(rows), G_ptr, row_off.ctypes.data,
+                                                   stream), "gkmhip_gram_rows_packed")
+
     def gram_rows_full(self, rows, G_ptr, ld, local_rows=True, stream=0):
         rows = np.ascontiguousarray(rows, dtype=np.int32)
         self._chk(self.lib.gkmhip_gram_rows_full(self.handle, rows.ctypes.data, len(rows), int(local_rows), G_ptr, ld,
@@ -318,7 +329,8 @@ class GramContext:
                   "gkmhip_normalize")
 
     def assemble_normalize(self, slabs_ptr, lds, slot_ptr, K_ptr, ld, sq_ptr, symmetric=False, stream=0):
-        """Un-permute (matrix row a = row slot[a] of the gathered slabs) + normalise in one pass."""
+        """Un-permute (matrix row a = row slot[a] of the gathered slabs; with lds == 1 slot[a] is the element offset
+        at which row a starts: packed slabs) + normalise in one pass."""
         self._chk(self.lib.gkmhip_assemble_normalize(self.handle, slabs_ptr, lds, slot_ptr, K_ptr, ld, sq_ptr,
                                                      int(symmetric), stream), "gkmhip_assemble_normalize")
 
@@ -357,6 +369,7 @@ def cross_kernel(seqs, rows, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, devi
 
 
 _CTX_CACHE = {}
+_CTX_CACHE_LOCK = __import__("threading").Lock()   # init_many's workers insert and release concurrently
 
 
 def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, slot=0):
@@ -367,17 +380,21 @@ def cached_context(kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, slot
     never blocks on the other stream.  `slot` tells apart callers that work on the same device at the same time
     (gkmsvm.init_many with one worker per entry of `gpus`)."""
     key = (device, slot, kernel_type, L, k, d, int(M), float(H), float(gamma))
-    ctx = _CTX_CACHE.get(key)
-    if ctx is None or not ctx.handle:
-        ctx = _CTX_CACHE[key] = GramContext(kernel_type, L, k, d, M, H, gamma, device)
+    with _CTX_CACHE_LOCK:
+        ctx = _CTX_CACHE.get(key)
+        if ctx is None or not ctx.handle:
+            ctx = _CTX_CACHE[key] = GramContext(kernel_type, L, k, d, M, H, gamma, device)
     return ctx
 
 
 def release_cached_contexts(device=None, slot=None):
     """Close the cached contexts (all of them, or those of one device / slot): each keeps its device scratch --
     the tile-transposed output alone is ~0.6 GB at n = 10 000 -- for as long as it lives."""
-    for key in [k for k in _CTX_CACHE if (device is None or k[0] == device) and (slot is None or k[1] == slot)]:
-        _CTX_CACHE.pop(key).close()
+    with _CTX_CACHE_LOCK:
+        gone = [_CTX_CACHE.pop(key) for key in list(_CTX_CACHE)
+                if (device is None or key[0] == device) and (slot is None or key[1] == slot)]
+    for ctx in gone:     # (hipFree waits for the device: outside the lock)
+        ctx.close()
 
 
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,

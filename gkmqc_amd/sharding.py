@@ -3,7 +3,12 @@
 Row a costs ~ (a+1) column sequences, so equal row blocks are unbalanced.  Folded pairing:
 cut the rows into 2*G contiguous blocks; rank g owns blocks g and 2G-1-g -- equal row count
 (so equal all-gather send counts) and near-equal area.  The assembled matrix is obtained by
-an all-gather of the per-rank [rows_per_rank, N] slabs followed by an index permutation.
+an all-gather of the per-rank slabs followed by an index permutation.
+
+Packed slabs (round 4): only the cells j <= a of row a are computed and read, so a chunk's slab holds row a as
+a + 1 doubles, rows back to back; the folded pairing makes the packed size the same on every rank (and, chunk by
+chunk, within a few rows), every chunk slab is padded to the largest one -- the all-gather moves n^2 / (2G)
+doubles per rank instead of n^2 / G.  Twin of gkmqc_amd/csrc/gkm_shard.h (tests/test_sharding.py).
 """
 import numpy as np
 
@@ -71,3 +76,59 @@ def chunked_gather_index(n, world_size, chunks):
             slot_of_row[r] = (c * world_size + g) * pc + np.arange(len(r))
     assert (slot_of_row >= 0).all()
     return slot_of_row
+
+
+def packed_row_offsets(rows):
+    """Offset of each row of one chunk inside its packed slab (row a = a + 1 doubles, rows back to back); one
+    entry more than rows: the packed size of the chunk."""
+    off = np.zeros(len(rows) + 1, dtype=np.int64)
+    np.cumsum(np.asarray(rows, dtype=np.int64) + 1, out=off[1:])
+    return off
+
+
+def packed_chunk_elems(n, world_size, chunks):
+    """Doubles per chunk slab: the largest packed chunk over all ranks and chunks (the all-gather's send count)."""
+    pe = 1
+    for g in range(world_size):
+        parts, _ = chunked_layout(n, world_size, g, chunks)
+        for p in parts:
+            pe = max(pe, int((p.astype(np.int64) + 1).sum()))
+    return pe
+
+
+def auto_chunks(n, world_size):
+    """Chunks per rank when the caller does not say (twin of gkm_shard.h auto_chunks): the first of 4, 5, 3 whose
+    padded slab size is within 3 % of the best of the three -- 64-row groups dealt round robin leave some chunk with
+    one expensive group more than the others (n = 10 000 on 8 ranks: 21 % padding with 4 chunks, 4 % with 5)."""
+    if world_size <= 1:
+        return 1
+    cand = (4, 5, 3)
+    padded = [c * packed_chunk_elems(n, world_size, c) for c in cand]
+    for c, p in zip(cand, padded):
+        if p <= 1.03 * min(padded):
+            return c
+    return 4
+
+
+def packed_gather_offsets(n, world_size, chunks):
+    """offset[a]: where matrix row a starts inside the concatenation over chunks c of the all-gathered
+    [world_size][packed_chunk_elems] slabs."""
+    pe = packed_chunk_elems(n, world_size, chunks)
+    off = np.full(n, -1, dtype=np.int64)
+    for g in range(world_size):
+        parts, _ = chunked_layout(n, world_size, g, chunks)
+        for c, p in enumerate(parts):
+            off[p] = (c * world_size + g) * pe + packed_row_offsets(p)[:-1]
+    assert (off >= 0).all()
+    return off
+
+
+def allgather_bytes_per_rank(n, world_size, chunks, packed=True):
+    """Bytes one rank RECEIVES from its peers per matrix (what crosses xGMI into each GPU)."""
+    if world_size <= 1:
+        return 0
+    if packed:
+        per_chunk = packed_chunk_elems(n, world_size, chunks)
+    else:
+        per_chunk = chunked_layout(n, world_size, 0, chunks)[1] * n
+    return int(chunks * (world_size - 1) * per_chunk * 8)

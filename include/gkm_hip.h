@@ -82,6 +82,13 @@ int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int
 int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
                      int64_t ld, int32_t *P, int64_t ldp, void *stream);
 
+/* The same rows into a PACKED slab: row rows[i] is written to G + row_off[i] (host array of nrows element offsets),
+ * columns 0..rows[i] only -- rows[i] + 1 doubles, so rows may sit back to back.  This is the send buffer of the
+ * multi-GPU all-gather (gkmhip_gram_allgather; layout in gkmqc_amd/csrc/gkm_shard.h): only j <= a is ever read, and
+ * shipping n doubles per row moved twice the bytes (round 3). */
+int gkmhip_gram_rows_packed(gkmhip_ctx *ctx, const int *rows, int nrows, double *G, const int64_t *row_off,
+                            void *stream);
+
 /* Rectangular variant for prediction-style use (the batch-vs-support-vector call of the
  * reference, gkmkernel_kernelfunc_batch, src/libgkm.c:1115-1153): raw G(rows[i], j) for EVERY
  * uploaded sequence j (not only j <= a).  G needs ld >= n. */
@@ -132,13 +139,14 @@ int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
 
 /* ---- several GPUs, one host process (gkm_multi.hip) ----
  * Every context (one per device, same parameters, same sequences uploaded) computes the rows of its
- * folded row blocks; the row slabs are all-gathered over xGMI (RCCL ncclAllGather on communicators
+ * folded row blocks; the row slabs -- packed, a + 1 doubles for row a: n^2 / (2 nctx) doubles per rank and
+ * matrix -- are all-gathered over xGMI (RCCL ncclAllGather on communicators
  * made by ncclCommInitAll; peer copies when several contexts share one device or RCCL cannot be
  * loaded; GKM_ALLGATHER=rccl|p2p forces one), then every device un-permutes and normalises its copy.
  * K[g]: device pointer ON ctxs[g]'s DEVICE to an n x ld matrix that receives K (lower triangle +
  * unit diagonal, the upper triangle too if symmetric != 0) -- the same matrix, bit for bit, as
  * gkmhip_gram_rows + gkmhip_normalize produce on one device.  chunks: slabs per rank whose transfer
- * overlaps the next slab's kernel (0 = default 4).  One host thread per device for the duration of
+ * overlaps the next slab's kernel (0 = chosen from (n, nctx): 4, 5 or 3, whichever pads the slabs least).  One host thread per device for the duration of
  * the call; blocks until every device holds the matrix.  This is what feeds the GPU-resident
  * cross-validation (include/gkm_svm.h) from an N-GPU matrix; the reference's consumer is
  * scripts/gkmsvm.py:104-122. */
@@ -153,6 +161,8 @@ void gkmhip_release_comms(void);
 /* hipMalloc calls gkmhip_gram_allgather has made so far in this process (a second call of the same shape makes
  * none) */
 long gkmhip_allgather_alloc_count(void);
+/* bytes every rank RECEIVED from its peers in the most recent gkmhip_gram_allgather (per matrix) */
+long long gkmhip_allgather_bytes_per_rank(void);
 /* What the most recent successful gkmhip_gram_allgather measured with HIP events on its own streams:
  * out[0] = ranks, out[1] = chunks, out[2] = transport (0 none, 1 peer copies, 2 RCCL), then for every rank
  * {kernel ms summed over its chunks, transfer ms summed over its chunks, un-permute + normalise ms, l-mer
@@ -160,8 +170,9 @@ long gkmhip_allgather_alloc_count(void);
 int gkmhip_allgather_stats(double *out, int cap);
 
 /* Un-permutation + normalisation in one pass: matrix row a is row slot_of_row[a] (device array, n
- * int64) of `slabs` (device, leading dimension lds, raw values); K receives what gkmhip_normalize
- * would produce, sqnorm (device, n doubles) the self norms. */
+ * int64) of `slabs` (device, leading dimension lds >= n, raw values); with lds == 1 slot_of_row[a] is the
+ * element offset at which row a starts (packed slabs: gkmhip_gram_rows_packed).  K receives what
+ * gkmhip_normalize would produce, sqnorm (device, n doubles) the self norms. */
 int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds, const int64_t *slot_of_row,
                               double *K, int64_t ld, double *sqnorm, int symmetric, void *stream);
 

@@ -48,6 +48,8 @@ def test_one_json_line_with_roofline_end_to_end_and_cpu_baseline(built, forced_d
     e2e = d["end_to_end"]
     assert e2e["boundary_ms"] > 0 and e2e["pipeline_ms"] > 0 and 0.0 <= e2e["pipeline_auc"] <= 1.0
     assert "workload" in d["config"] and "model" not in d["config"]
+    # the parity gate is part of every line; a custom size has no reference digest and says so (never a guess)
+    assert d["parity"]["fixture"] is None and d["parity"]["sha256_matches_reference"] is None and "parity_failed" not in d
     if forced_dist:
         assert d["config"]["env"].get("GKM_BENCH_FORCE_DIST") == "1"   # GKM_* knobs are on record
 
@@ -71,6 +73,33 @@ def test_plain_gpus_2_launches_its_own_ranks(built, assembly):
     assert sum(rf["comparisons_per_rank"]) == pytest.approx(2.0 * 290 * 290 * (800 * 801 / 2), rel=1e-9)
     if assembly == "cabi":   # the buffers of gkmhip_gram_allgather are kept between calls (warm-up call included)
         assert rf["allgather_hipmalloc_calls_in_timed_region"] == 0
+    # packed slabs: what a rank receives is about half of what full-width rows cost, and both are in the line
+    assert 0 < rf["allgather_bytes_per_rank"] < 0.62 * rf["allgather_bytes_full_width_rows"]
+    assert rf["allgather_GBps_per_rank"] > 0
+    assert d["parity"]["checked_copies"] == 2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("how", ["ok", "fail", "kill"])
+def test_gpus_2_measures_the_c_abi_entry_and_falls_back_to_torch(built, how):
+    """`python bench.py --gpus 2` (--assembly auto): the line's numbers come from the product's one-process entry
+    gkmhip_gram_allgather, run in a fresh child, the torch.distributed ranks are the cross-check under also.torch_dist.
+    A child that fails (GKM_BENCH_CABI_FAIL) or is killed at its timeout does not cost the run: the line says so and
+    carries the torch numbers."""
+    env = {"GKM_BENCH_SHARE_GPU": "1", "GKM_BENCH_BACKEND": "gloo"}
+    if how == "fail":
+        env["GKM_BENCH_CABI_FAIL"] = "1"
+    if how == "kill":
+        env["GKM_BENCH_CABI_TIMEOUT"] = "0.5"
+    d = _one_line(_run(["--gpus", "2", "--no-cpu-baseline"] + SMALL, env))
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["ranks"] == 2
+    if how == "ok":
+        assert d["config"]["transport"] == "p2p" and d["assembly"].startswith("cabi") and "cabi_error" not in d
+        t = d["also"]["torch_dist"]
+        assert t["transport"] == "gloo" and t["ranks"] == 2 and t["value"] > 0 and t["allgather_bytes_per_rank"] > 0
+    else:
+        assert d["config"]["transport"] == "gloo" and "FALLBACK" in d["assembly"]
+        assert ("injected" in d["cabi_error"]) if how == "fail" else ("killed" in d["cabi_error"])
 
 
 def test_headline_roofline_uses_only_a_matching_pmc_summary(tmp_path, monkeypatch):
@@ -115,7 +144,7 @@ def test_multi_gpu_roofline_fields():
 def test_launcher_stops_the_other_ranks_when_one_fails():
     """A rank that dies before the process group forms must not leave its peers (and the parent) waiting: the
     parent polls every child, ends the rest on the first non-zero exit and reports failure within seconds; the
-    same for the overall timeout.  Rank 0's stdout is relayed only on success."""
+    same for the overall timeout."""
     import time
     import types
     sys.path.insert(0, ROOT)
@@ -159,3 +188,57 @@ def test_plain_gpus_n_without_gpus_fails_cleanly():
         pytest.skip("needs a box without GPUs")
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--n-pos", "20", "--n-neg", "20"], timeout=300)
     assert r.returncode != 0 and r.stdout.decode().strip() == ""
+
+
+def test_parity_gate_hashes_the_cells_the_reference_writes(tmp_path, monkeypatch):
+    """bench.parity_check: SHA-256 of the strict lower triangle, row-major, against the fixture's digest (the layout
+    tests/golden/make_golden.py --full writes) + the sampled cells; one flipped bit anywhere below the diagonal fails
+    it, the upper triangle and the diagonal do not take part."""
+    import hashlib
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    rng = np.random.default_rng(5)
+    n = 97
+    K = np.tril(rng.random((n, n)), -1) + np.eye(n)
+    i, j = np.tril_indices(n, -1)
+    tri = K[i, j]
+    sel = rng.choice(tri.size, 200, replace=False)
+    os.makedirs(tmp_path / "tests" / "golden")
+    np.savez(tmp_path / "tests" / "golden" / "c2_full_digest.npz",
+             sha256=np.frombuffer(hashlib.sha256(tri.tobytes()).digest(), dtype=np.uint8), sample_idx=sel, sample_val=tri[sel])
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    p = bench.parity_check("c2", False, K)
+    assert p["ok"] is True and p["sha256_matches_reference"] is True and p["max_rel_err_sample"] == 0.0
+    K2 = K.copy()
+    K2[3, 50] = 7.0                      # upper triangle: not a cell the reference writes
+    K2[5, 5] = 0.5                       # diagonal: not hashed
+    assert bench.parity_check("c2", False, K2)["ok"] is True
+    K2[60, 7] = np.nextafter(K2[60, 7], 2.0)
+    bad = bench.parity_check("c2", False, K2)
+    assert bad["ok"] is False and bad["sha256_matches_reference"] is False and bad["max_rel_err_sample"] < 1e-12
+    assert bench.parity_check("c2", True, K)["ok"] is None            # custom size: no digest applies
+    assert bench.parity_check("d600", False, K)["fixture"] is None    # a workload without a fixture
+    both = bench.merge_parity([p, bad])
+    assert both["ok"] is False and both["checked_copies"] == 2 and both["sha256_matches_reference_per_copy"] == [True, False]
+
+
+def test_merge_of_the_two_assemblies():
+    """--assembly auto: the C-ABI line is the line; torch is the cross-check; a failed or parity-failing C-ABI child
+    is named in `cabi_error` and the torch numbers take its place."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cabi = {"value": 9.0, "config": {"ranks": 8, "transport": "rccl"}, "roofline": {"allgather_ms": 2.0}, "parity": {"ok": True}}
+    tor = {"value": 8.0, "config": {"ranks": 8, "transport": "rccl"}, "roofline": {"allgather_ms": 3.0}, "parity": {"ok": True}}
+    out, rc = bench.merge_assemblies(dict(cabi), None, dict(tor), None)
+    assert rc == 0 and out["value"] == 9.0 and out["also"]["torch_dist"]["value"] == 8.0 and "cabi_error" not in out
+    out, rc = bench.merge_assemblies(None, "killed after 300 s", dict(tor), None)
+    assert rc == 0 and out["value"] == 8.0 and out["cabi_error"] == "killed after 300 s" and "FALLBACK" in out["assembly"]
+    out, rc = bench.merge_assemblies(dict(cabi, parity_failed=True, value=None), None, dict(tor), None)
+    assert rc == 0 and out["value"] == 8.0 and "parity" in out["cabi_error"] and out["also"]["cabi"]["value"] is None
+    out, rc = bench.merge_assemblies(dict(cabi), None, None, "ranks failed")
+    assert rc == 0 and out["value"] == 9.0 and out["also"]["torch_dist"] == {"error": "ranks failed"}
+    out, rc = bench.merge_assemblies(None, "x", dict(tor, parity_failed=True, value=None), None)
+    assert rc == 3 and out["value"] is None
+    assert bench.merge_assemblies(None, "x", None, "y") == (None, 1)
+    assert bench._strip_flag(["--gpus", "2", "--assembly", "auto", "--check", "--assembly=torch"], "--assembly") == ["--gpus", "2", "--check"]

@@ -467,6 +467,41 @@ def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
         assert torch.equal(low["K"][nctx - 1], torch.tril(one))
 
 
+@pytest.mark.parametrize("kernel", ["bitslice", "direct"])
+def test_packed_row_slabs_hold_the_same_cells(dev, quirk_seqs, kernel):
+    """gkmhip_gram_rows_packed (the send buffer of the multi-GPU all-gather): row rows[i] at G + row_off[i], columns
+    0..rows[i] only, rows back to back -- the same raw values as gkmhip_gram_rows writes at full width, nothing
+    outside the rows' own cells touched, for both kernels, an arbitrary ascending row subset and ragged lengths."""
+    import torch
+    from gkmqc_amd import sharding
+    seqs, _ = quirk_seqs
+    ragged = helpers.synth_codes(150, 150, 300, (150, 700))
+    for problem, (t, L, k, d) in ((seqs, (4, 11, 7, 3)), (ragged, (2, 10, 6, 3))):
+        n = len(problem)
+        ctx = dev.GramContext(t, L, k, d)
+        try:
+            ctx.set_kernel(dev.KERNEL_BITSLICE if kernel == "bitslice" else dev.KERNEL_DIRECT)
+            stream = torch.cuda.current_stream().cuda_stream
+            ctx.set_sequences(problem, stream)
+            full = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+            ctx.gram_rows(np.arange(n), full.data_ptr(), n, None, 0, False, stream)
+            rows = np.array(sorted(set(np.random.default_rng(3).integers(0, n, n // 2).tolist()) | {0, n - 1}), dtype=np.int32)
+            off = sharding.packed_row_offsets(rows) + 5           # (not at the start of the buffer)
+            slab = torch.full((int(off[-1]) + 7,), -3.25, dtype=torch.float64, device="cuda")
+            ctx.gram_rows_packed(rows, slab.data_ptr(), off, stream)
+            torch.cuda.synchronize()
+            got, want = slab.cpu().numpy(), full.cpu().numpy()
+            assert (got[:5] == -3.25).all() and (got[int(off[-1]):] == -3.25).all()
+            for i, a in enumerate(rows):
+                assert (got[off[i]:off[i] + a + 1] == want[a, :a + 1]).all(), (kernel, a)
+            bad = off.copy()
+            bad[1] = bad[0] + rows[0]                              # row 1 would overlap row 0's last cell
+            with pytest.raises(dev.GkmError):
+                ctx.gram_rows_packed(rows, slab.data_ptr(), bad, stream)
+        finally:
+            ctx.close()
+
+
 def test_one_process_assembly_keeps_its_buffers(dev):
     """gkmhip_gram_allgather keeps each rank's slab, gathered slabs, gather index, streams and events between calls of
     the same shape (bin/gkmqc.py asks for ~20 matrices of one size per run; hipMalloc / hipFree synchronise the

@@ -152,14 +152,17 @@ def test_product_does_not_reference_the_oracle():
 
 
 def test_no_timing_variants_in_the_product(built):
-    """The ablation kernels (template parameter VARIANT != 0: parts of the work skipped, WRONG results) and
-    the GKM_VARIANT switch that selects them exist only in -DGKM_TIMING_VARIANTS builds under
-    build_variants/ (tools/variants.sh); the drop-in library must hold VARIANT = 0 instantiations only."""
+    """The ablation kernels of rounds 1-3 (a fifth template parameter VARIANT != 0: parts of the work skipped, WRONG
+    results) and the GKM_VARIANT switch that selected them are gone from the source (tools/variants.sh rebuilds them
+    from revision a4bed73 into build_variants/): the drop-in library holds four-parameter instantiations only, and
+    neither the library nor the kernel source knows the switch."""
     import re
     blob = open(os.path.join(ROOT, "gkmqc_amd", "bin", "gkmkern_pylib.so"), "rb").read()
-    found = re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELi[012]ELi(\d+)EEv6BsArgs", blob)
-    assert len(found) > 100 and set(found) == {b"0"}, set(found)
+    found = re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELi[0123]E(Li\d+E)?Ev6BsArgs", blob)
+    assert len(found) > 100 and set(found) == {b""}, set(found)
     assert b"GKM_VARIANT" not in blob
+    for f in ("gkm_device.hip", "gkm_bitslice.h", "gkm_pack.h"):
+        assert "VARIANT" not in open(os.path.join(ROOT, "gkmqc_amd", "csrc", f)).read(), f
 
 
 @pytest.mark.parametrize("value", ["0,x", "7,", "-1", "99", "two"])

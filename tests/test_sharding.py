@@ -1,7 +1,7 @@
 """Row sharding + assembly of the Gram matrix across ranks, on CPU with the
 gloo backend (world_size 2 and 3).  The per-rank kernel is replaced by the oracle here so the
-test exercises exactly the plumbing bench.py uses: folded row blocks -> fixed-size slabs ->
-all_gather_into_tensor -> row permutation -> normalisation."""
+test exercises exactly the plumbing bench.py uses: folded row blocks -> PACKED fixed-size slabs (row a = a + 1
+doubles) -> all_gather_into_tensor -> row offsets -> normalisation."""
 import os
 import socket
 import sys
@@ -72,6 +72,40 @@ def test_cpp_layout_matches_python(built):
                         buf = np.zeros(pc + 1, dtype=np.int32)
                         cnt = lib.shardprobe_part(n, world, rank, chunks, c, buf.ctypes.data_as(ctypes.c_void_p))
                         assert cnt == len(parts[c]) and (buf[:cnt] == parts[c]).all()
+                # the packed slabs (row a = a + 1 doubles): slab size and where every row starts
+                lib.shardprobe_packed_chunk_elems.restype = ctypes.c_longlong
+                assert lib.shardprobe_packed_chunk_elems(n, world, chunks) == sharding.packed_chunk_elems(n, world, chunks)
+                off = np.zeros(n, dtype=np.int64)
+                lib.shardprobe_packed_gather_offsets(n, world, chunks, off.ctypes.data_as(ctypes.c_void_p))
+                assert (off == sharding.packed_gather_offsets(n, world, chunks)).all()
+            assert lib.shardprobe_auto_chunks(n, world) == sharding.auto_chunks(n, world)
+
+
+def test_packed_layout_properties():
+    """Packed slabs: every row's a + 1 cells lie inside its chunk's slab, no two rows overlap, every rank sends the
+    same count, and the bytes are about half of what full-width rows cost."""
+    from gkmqc_amd import sharding
+    for n in (5, 63, 400, 2000, 10000):
+        for world in (1, 2, 3, 8):
+            for chunks in (1, 2, 4, 5):
+                pe = sharding.packed_chunk_elems(n, world, chunks)
+                off = sharding.packed_gather_offsets(n, world, chunks)
+                order = np.argsort(off)
+                ends = off[order] + order + 1            # row a occupies [off[a], off[a] + a + 1)
+                assert (ends[:-1] <= off[order][1:]).all() and ends[-1] <= chunks * world * pe
+                for r in range(world):
+                    parts, _ = sharding.chunked_layout(n, world, r, chunks)
+                    for c, p in enumerate(parts):
+                        ro = sharding.packed_row_offsets(p)
+                        assert ro[-1] <= pe, "a chunk fits its slab"
+                        assert (off[p] == (c * world + r) * pe + ro[:-1]).all()
+    # what crosses the links: half of round 3's full-width rows (700 -> ~350 MB per GPU for config 2 on 8 ranks)
+    for n, world in ((10000, 8), (10000, 4), (10000, 2), (20000, 8)):
+        chunks = sharding.auto_chunks(n, world)
+        packed = sharding.allgather_bytes_per_rank(n, world, chunks)
+        full = sharding.allgather_bytes_per_rank(n, world, chunks, packed=False)
+        ideal = (world - 1) / world * n * n / 2 * 8
+        assert packed < 0.53 * full and packed < 1.05 * ideal, (n, world, chunks, packed, full, ideal)
 
 
 def _free_port():
@@ -90,17 +124,23 @@ def _worker(rank, world, port, raw_path, n, out_path):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     raw = np.load(raw_path)                     # raw G(a, j), lower triangle + diagonal
     chunks = 3                                  # same layout functions and call order as bench.py
-    parts, pc = sharding.chunked_layout(n, world, rank, chunks)
-    slab = torch.zeros((chunks, pc, n), dtype=torch.float64)
-    gathered = torch.zeros((chunks, world * pc, n), dtype=torch.float64)
+    parts, _ = sharding.chunked_layout(n, world, rank, chunks)
+    pe = sharding.packed_chunk_elems(n, world, chunks)
+    slab = torch.full((chunks, pe), float("nan"), dtype=torch.float64)        # padding is never read
+    gathered = torch.zeros((chunks, world * pe), dtype=torch.float64)
     pending = []
     for c in range(chunks):
-        slab[c, : len(parts[c])] = torch.from_numpy(raw[parts[c]])   # this rank's rows only
+        ro = sharding.packed_row_offsets(parts[c])
+        for i, a in enumerate(parts[c]):                                     # this rank's rows only, j <= a
+            slab[c, ro[i]:ro[i] + a + 1] = torch.from_numpy(raw[a, :a + 1])
         pending.append(dist.all_gather_into_tensor(gathered[c], slab[c], async_op=True))
     for w in pending:
         w.wait()
-    slot = torch.from_numpy(sharding.chunked_gather_index(n, world, chunks))
-    full = torch.index_select(gathered.view(chunks * world * pc, n), 0, slot)
+    off = sharding.packed_gather_offsets(n, world, chunks)
+    flat = gathered.view(-1)
+    full = torch.zeros((n, n), dtype=torch.float64)
+    for a in range(n):
+        full[a, :a + 1] = flat[off[a]:off[a] + a + 1]
     if rank == 0:
         np.save(out_path, full.numpy())
     dist.barrier()

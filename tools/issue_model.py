@@ -41,7 +41,7 @@ def disassemble(obj, kernel):
     subprocess.check_call([os.path.join(LLVM, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fat,
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + elf], stderr=subprocess.DEVNULL)
     w, L, d, pk = kernel
-    sym = "_Z15k_gram_bitsliceILi%dELi%dELi%dELi%dELi0EEv6BsArgs" % (w, L, d, pk)
+    sym = "_Z15k_gram_bitsliceILi%dELi%dELi%dELi%dEEv6BsArgs" % (w, L, d, pk)
     out = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--disassemble-symbols=" + sym, elf]).decode()
     lines, addrs = [], []
     for raw in out.splitlines():

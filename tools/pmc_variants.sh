@@ -1,6 +1,8 @@
 #!/bin/bash
 # rocprofv3 PMC passes of the hot kernel for the product build and for ablation builds (GPU box):
 # where do the cycles of the hit path go?   tools/pmc_variants.sh "0 32 16" [workload]
+# (variants != 0: build_variants/lib_timing.so, built by tools/variants.sh from revision a4bed73 -- the ablation
+# branches left the source tree in round 4)
 set -u
 VARS=${1:-"0 32"}
 WL=${2:-c2}
