@@ -33,6 +33,7 @@
 #include "gkm_pack.h"
 
 #define GKM_MAXD1 13 /* d <= 12 */
+#define GKM_SCRATCH_SLOTS 2 /* per-launch scratch sets of a context (gkmhip_set_scratch_slot) */
 
 /* ------------------------------------------------------------------ errors */
 static thread_local std::string g_err;
@@ -78,6 +79,8 @@ extern "C" int gkmhip_set_current_device(int device)
     HIPCHK(hipSetDevice(device));
     return 0;
 }
+
+void gkm_release_pipe_streams(); /* (the copy-out pipeline's cached streams, defined with the pipeline below) */
 
 /* Pinned staging for device-to-host copies, kept for the life of the process: the pipeline
  * calls the boundary once per peak subset (20x per run, bin/gkmqc.py:341-343) and pinning
@@ -160,6 +163,7 @@ extern "C" void gkmhip_release_host_cache(void)
                 b->cap = 0;
             }
     }
+    gkm_release_pipe_streams();
     std::lock_guard<std::mutex> lock(g_stage_mutex);
     for (int s = 0; s < STAGE_SLOTS; s++) {
         for (int i = 0; i < 2; i++) {
@@ -228,7 +232,7 @@ struct gkmhip_ctx {
         {
             rows.release(); rowoff.release(); tables.release(); rowplanes.release(); rowpk.release(); S.release();
         }
-    } scratch[2];
+    } scratch[GKM_SCRATCH_SLOTS];
     int sel = 0;
     DevBuf<double> sq;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -275,7 +279,8 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     /* (hipFree waits for the work that may still use the buffers; no separate device-wide wait) */
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release();
-    ctx->scratch[0].release(); ctx->scratch[1].release(); ctx->sq.release();
+    for (auto &scr : ctx->scratch) scr.release();
+    ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -286,7 +291,7 @@ extern "C" int gkmhip_device_of(const gkmhip_ctx *ctx) { return ctx ? ctx->devic
 
 extern "C" int gkmhip_set_scratch_slot(gkmhip_ctx *ctx, int slot)
 {
-    if (!ctx || slot < 0 || slot > 1) return set_err_msg("bad scratch slot", 2);
+    if (!ctx || slot < 0 || slot >= GKM_SCRATCH_SLOTS) return set_err_msg("bad scratch slot", 2);
     ctx->sel = slot;
     return 0;
 }
@@ -581,6 +586,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     const int j0 = A.tile_cbeg[tile] + (int)((int64_t)blockIdx.x - A.tile_soff[tile]), j1 = j0 + 1;
     const int nrows = A.tile_nrows[tile];
     constexpr int NE = NSLOT / 64; /* row slots a lane finishes in the epilogue */
+    /* A tile with at most NSLOT / 2 rows (600-bp rows: 32 per tile) keeps TWO copies of every profile, NSLOT / 2 slots
+     * apart, and the epilogue adds them: the hits of odd source lanes go to the second copy (the host puts the offset
+     * into those lanes' piece entries, gram_launch), so the ds_add_u32 of a trip spread over twice the addresses --
+     * 88 % of all hits have m = d and 64 lanes were adding into 32 words. */
+    const bool two_copies = 2 * nrows <= NSLOT;
 
     uint32_t Ahi[W], Alo[W], AV[W];
 #pragma unroll
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         const int ceven = (nB & 1) ? 0 : 1;
 #pragma unroll
         for (int m = 0; m <= D; m++)
-            for (int rs = lane; rs < nrows; rs += 64) accl[m * NSLOT + rs] = 0u;
+            for (int rs = lane; rs < (two_copies ? NSLOT : nrows); rs += 64) accl[m * NSLOT + rs] = 0u;
         int s_n = 0; /* records in the hit list (wave-uniform) */
 
         /* One hit -> accl[m][row slot] += wa * wb.  (meta + sel, bit) name the row lane r, the lane position
@@ -811,17 +821,22 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             const int rs = k * 64 + lane;
             const int row = rs < nrows ? A.tile_row[tile * gkmpack::MAX_ROWS + rs] : -1;
             if (row < 0 || (j > row && !A.out.write_all)) continue;
+            /* the profile: both copies where there are two (uint32 addition: the int32 wrap-around of the
+             * reference's accumulator, libgkm.c:338, is kept) */
+            uint32_t prof[D + 1];
+#pragma unroll
+            for (int m = 0; m <= D; m++) prof[m] = accl[m * NSLOT + rs] + (two_copies ? accl[m * NSLOT + rs + NSLOT / 2] : 0u);
             /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
             double g = 0.0;
 #pragma unroll
-            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)accl[m * NSLOT + rs];
+            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)prof[m];
             const int64_t r = A.out.local_rows ? A.tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
             if (A.out.diag && j == row) A.out.diag[row] = g;
             if (A.S) A.S[(A.tile_soff[tile] + (j - A.tile_cbeg[tile])) * NSLOT + rs] = g;
             if (A.out.P) {
 #pragma unroll
                 for (int m = 0; m <= D; m++)
-                    A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)accl[m * NSLOT + rs];
+                    A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)prof[m];
             }
         }
     }
@@ -1165,7 +1180,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             /* byte offset of the row slot in accl[m][.]; the row l-mer at lane position i0 is |c0 - i0| l-mers
              * away from its sequence's centre l-mer, c0 > -2048 is stored with a bias of 2048 so that the
              * kernel's unsigned |a - b| applies */
-            const uint32_t slot4 = (uint32_t)pc.slot * 4u;
+            /* second profile copy (k_gram_bitslice two_copies): odd lanes of a tile with at most slots / 2 rows */
+            const int tile_of = pc.lane / 64;
+            const bool second = 2 * pk.tile_nrows[(size_t)tile_of] <= slots && (pc.lane & 1);
+            const uint32_t slot4 = ((uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u)) * 4u;
             const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
             if (packed) {
                 lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
@@ -1206,6 +1224,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
+        /* (The tables and row planes on a second stream and untile on a third, so that the Gram kernels of the drop-in
+         * call's row blocks follow each other with nothing in between, was built and measured in round 4: k_untile's
+         * 33 KB workgroups then wait for room beside the next block's Gram kernel -- its 28 waves per CU leave 17 KB of
+         * LDS -- and finish only when it does; the copies start one block late: 90.6 instead of 81.4 ms for the call.) */
         /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
          * so that the lane field of a record's origin word is the lane's byte offset (gkm_bitslice.h pack_meta) */
         const int rpw = 32;
@@ -1478,18 +1500,110 @@ static void cut_pieces(int r0, int r1, size_t bytes, std::vector<RowPiece> &out)
     }
 }
 
-struct StreamPair { /* destroyed on every path out of the function that owns it */
-    hipStream_t a = nullptr, b = nullptr;
-    ~StreamPair()
+struct StreamSet { /* destroyed on every path out of the function that owns it */
+    hipStream_t s[4] = {nullptr, nullptr, nullptr, nullptr};
+    int create(int count)
     {
-        if (a) (void)hipStreamDestroy(a);
-        if (b) (void)hipStreamDestroy(b);
+        for (int i = 0; i < count; i++) HIPCHK(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+        return 0;
+    }
+    ~StreamSet()
+    {
+        for (hipStream_t x : s)
+            if (x) (void)hipStreamDestroy(x);
     }
 };
 
+/* The copy-out pipeline's streams, kept per device for the life of the process (gkmhip_release_host_cache frees them)
+ * and PROVEN to run beside each other.  HIP maps streams onto a handful of hardware queues (4 by default) in creation
+ * order, and two streams that land on one queue execute in order: round 4's first version created four streams per
+ * call, the copy stream shared the Gram stream's queue, and every device-to-host copy of the call waited for the LAST
+ * Gram kernel (first piece in staging at 84 ms of 92, tools/boundary_ab.py --trace).  So: a candidate stream is kept
+ * only if a tiny copy on it completes while a 2-ms spin kernel is still running on the compute stream; candidates
+ * that fail stay alive until the search is over, so that the next one lands on another queue. */
+__global__ void k_spin(long long ticks, unsigned *sink)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) { }
+    if (ticks == 1234567) sink[0] = 1u;
+}
+
+/* what the drop-in call's copy-out pipeline measured last time (gram_part_to_host_rows cuts its row blocks by it) */
+static struct {
+    std::mutex m;
+    double scatter_Bps_per_thread = 0, copy_Bps = 0, cmp_per_s = 0;
+} g_ship;
+
+struct PipeStreams {
+    hipStream_t compute = nullptr, copy = nullptr;
+    int probes = 0;
+    bool copy_beside = false; /* proven to run beside `compute` */
+};
+static std::mutex g_pipe_mutex;
+static PipeStreams g_pipe[64];
+
+static bool runs_beside(hipStream_t busy, hipStream_t other, unsigned *d_word, unsigned *h_word)
+{
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, busy, (long long)200000, d_word); /* 2 ms at 100 MHz */
+    bool beside = false;
+    if (hipMemcpyAsync(h_word, d_word + 1, sizeof(unsigned), hipMemcpyDeviceToHost, other) == hipSuccess &&
+        hipStreamSynchronize(other) == hipSuccess)
+        beside = hipStreamQuery(busy) == hipErrorNotReady;
+    (void)hipStreamSynchronize(busy);
+    return beside;
+}
+
+static int pipe_streams(int device, PipeStreams **out)
+{
+    if (device < 0 || device >= 64) return set_err_msg("device ordinal out of range", 2);
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    PipeStreams &P = g_pipe[device];
+    *out = &P;
+    if (P.compute) return 0;
+    unsigned *d_word = nullptr, *h_word = nullptr;
+    HIPCHK(hipMalloc((void **)&d_word, 2 * sizeof(unsigned)));
+    HIPCHK(hipHostMalloc((void **)&h_word, sizeof(unsigned), hipHostMallocPortable));
+    HIPCHK(hipStreamCreateWithFlags(&P.compute, hipStreamNonBlocking));
+    std::vector<hipStream_t> rejected;
+    for (int attempt = 0; attempt < 6 && !P.copy_beside; attempt++) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+        P.probes++;
+        P.copy_beside = runs_beside(P.compute, c, d_word, h_word);
+        if (P.copy_beside || attempt == 5) P.copy = c; /* (the last candidate is kept even if it shares the queue) */
+        else rejected.push_back(c);
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipFree(d_word);
+    (void)hipHostFree(h_word);
+    if (!P.copy) return set_err_msg("cannot create the copy-out streams", 4);
+    if (getenv("GKM_TRACE"))
+        fprintf(stderr, "gkmhip: copy-out streams of device %d after %d probe(s): the copy stream %s the compute stream\n", device,
+                P.probes, P.copy_beside ? "runs beside" : "SHARES A QUEUE WITH");
+    return 0;
+}
+
+void gkm_release_pipe_streams()
+{
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    int caller = -1;
+    (void)hipGetDevice(&caller);
+    for (int d = 0; d < 64; d++) {
+        PipeStreams &P = g_pipe[d];
+        if (!P.compute) continue;
+        (void)hipSetDevice(d);
+        for (hipStream_t x : {P.compute, P.copy})
+            if (x) (void)hipStreamDestroy(x);
+        P = PipeStreams();
+    }
+    if (caller >= 0) (void)hipSetDevice(caller);
+}
+
+
 template <class Issue>
 static hipError_t ship_pieces(const std::vector<RowPiece> &pieces, double *const stage[2], hipStream_t sd, double **rows,
-                              int nthreads, Issue issue, double *t_wait, double *t_scatter)
+                              int nthreads, Issue issue, double *t_wait, double *t_scatter,
+                              std::vector<double> *ready_at = nullptr)
 {
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const size_t NP = pieces.size();
@@ -1498,6 +1612,7 @@ static hipError_t ship_pieces(const std::vector<RowPiece> &pieces, double *const
         const double tw = now();
         e = hipStreamSynchronize(sd); /* piece q is in stage[q & 1] */
         if (e != hipSuccess) break;
+        if (ready_at) ready_at->push_back(now());
         if (q + 1 < NP) e = issue(q + 1);
         const double ts = now();
         if (t_wait) *t_wait += ts - tw;
@@ -1543,25 +1658,61 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
 
     /* Row blocks (one Gram launch each) and copy pieces (one staging rectangle each).
      * Several devices: blocks of at most 1/(4 nparts) of the triangle's area, dealt round-robin, one piece each.
-     * One device: every launch ends with a drain (a wave lives ~0.6 ms) and the LAST block's copy and scatter
-     * cannot overlap anything, so the blocks shrink geometrically -- 1/2, 1/4, ... of the area, the last ones
-     * 2-5 % -- and a block travels in as many staging-sized pieces as it needs: 6 launches instead of 13 for
-     * 10 000 rows and a short tail, 87 instead of 90 ms (GKM_EQUAL_BLOCKS=1 keeps the equal blocks, for A/B runs). */
+     * One device: every launch costs ~1 ms (ramp and drain: a wave lives ~0.6 ms), the copy-out of a block overlaps
+     * the Gram kernels of the blocks behind it, and the LAST block's copy and scatter overlap nothing.  So: as few
+     * blocks as the copy-out can keep up with.  With T the time the Gram kernels need for the whole triangle and S the
+     * time the copy-out needs for all of it (`nthreads` host threads scatter the rows: the caller's -@, 1 in gkmQC's
+     * default), a first block of 1 / (1 + S/T) of the area is shipped just when the rest has been computed; the rest
+     * is cut the same way, down to a last block of ~5 %.  T and S come from what the previous call of the process
+     * measured (g_ship), estimates before that.  16 threads, n = 10 000: 0.80 / 0.16 / 0.04 of the area -- 3 launches
+     * instead of round 3's 6 halvings, 79.5 instead of 81.7 ms for the call (tools/boundary_ab.py; profiles/r4_boundary_ab*);
+     * one thread: seven blocks from 0.36 down.  (GKM_EQUAL_BLOCKS=1 keeps the equal blocks of round 1, for A/B runs.) */
     std::vector<RowPiece> blocks, pieces;
     std::vector<int> block_of; /* piece -> block */
     const bool geometric = nparts == 1 && getenv("GKM_EQUAL_BLOCKS") == nullptr;
+    /* (whole rows as ONE linear copy per piece instead of a pitched copy of the columns [0, r1) -- twice the bytes --
+     * was measured in round 4: 102 instead of 96 ms on the same schedule) */
     const double total_area = (double)n * n / 2.0;
     const double area_cap = total_area / std::max(12, 4 * nparts);
     int index = 0;
     double left = total_area, target = total_area / 2.0;
+    double ship_ratio; /* S / T */
+    {
+        std::lock_guard<std::mutex> lock(g_ship.m);
+        const double bytes = total_area * 8.0;
+        /* (before anything has been measured: one thread moves ~15-20 GB/s into pageable memory, sixteen ~60) */
+        const double per_thread = g_ship.scatter_Bps_per_thread > 0 ? g_ship.scatter_Bps_per_thread : 15.0e9 / sqrt((double)nthreads);
+        const double ship_Bps = std::min(per_thread * nthreads, g_ship.copy_Bps > 0 ? g_ship.copy_Bps : 50.0e9);
+        const double cmp_rate = g_ship.cmp_per_s > 0 ? g_ship.cmp_per_s : 1.0e14;
+        const double cmp = ctx->h_cum_n.empty() ? 0.0 : ctx->h_cum_n[(size_t)n] * ctx->h_cum_n[(size_t)n]; /* ~2 n_a n_j over j <= a */
+        ship_ratio = cmp > 0 ? (bytes / ship_Bps) / (cmp / cmp_rate) : 0.5;
+    }
+    /* (1.3: a piece is copied, THEN scattered; only the copy of the next piece overlaps the scatter) */
+    const double first_share = std::min(0.8, std::max(0.3, 1.0 / (1.0 + 1.3 * ship_ratio)));
+    /* GKM_BLOCK_FRACTIONS="0.7,0.2" (experiments): the blocks' shares of the triangle's area, the last block takes the rest */
+    std::vector<double> fractions;
+    if (const char *bf = getenv("GKM_BLOCK_FRACTIONS"))
+        for (const char *q = bf; *q;) {
+            char *end = nullptr;
+            const double v = strtod(q, &end);
+            if (end == q) break;
+            if (v > 0.0 && v < 1.0) fractions.push_back(v);
+            q = *end ? end + 1 : end;
+        }
+    size_t fi = 0;
     for (int r0 = 0; r0 < n;) {
         int r1 = r0 + 1;
-        if (geometric) {
-            if (left <= 0.05 * total_area) target = left; /* the rest in one go */
+        if (geometric && !fractions.empty()) {
+            target = fi < fractions.size() ? fractions[fi++] * total_area : left;
+            while (r1 < n && ((double)(r1 + 1) * (r1 + 1) - (double)r0 * r0) / 2.0 <= target) r1++;
+            if (fi > fractions.size() || n - r1 < 32) r1 = n;
+            if (fi == fractions.size()) fi++; /* the next block is the last one */
+            left -= ((double)r1 * r1 - (double)r0 * r0) / 2.0;
+        } else if (geometric) {
+            target = left <= 0.06 * total_area ? left : first_share * left; /* (the rest in one go) */
             while (r1 < n && ((double)(r1 + 1) * (r1 + 1) - (double)r0 * r0) / 2.0 <= target) r1++;
             if (n - r1 < 32) r1 = n;
             left -= ((double)r1 * r1 - (double)r0 * r0) / 2.0;
-            target = std::max(target / 2.0, 0.02 * total_area);
         } else {
             while (r1 < n && (size_t)(r1 + 1) * (size_t)(r1 + 1 - r0) * 8 <= want &&
                    ((double)(r1 + 1) * (r1 + 1) - (double)r0 * r0) / 2.0 <= area_cap)
@@ -1580,13 +1731,14 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     auto now = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double t0 = now();
     double t_wait = 0, t_scatter = 0;
-    /* (Alternating the blocks' Gram kernels between two streams, so that block b+1 fills the CUs block b's
-     * drain leaves idle, was measured: 107 instead of 89 ms for the 10 000-row call -- two tiles' worth of
-     * waves on a CU evict each other's packed rows from L1, as with the column-major block order.) */
-    StreamPair sp;
-    HIPCHK(hipStreamCreate(&sp.a));
-    HIPCHK(hipStreamCreate(&sp.b));
-    const hipStream_t sc = sp.a, sd = sp.b;
+    /* Two streams, kept per device and PROVEN to run beside each other (pipe_streams): sc carries the blocks' compute
+     * (tables, row planes, Gram kernel, untile, self norms, normalise: ~0.35 ms of small kernels per block boundary),
+     * sd the device-to-host copies.  (Alternating the blocks' Gram kernels between two streams was measured in round 2:
+     * 107 instead of 89 ms -- two tiles' worth of waves on a CU evict each other's packed rows from L1; moving the small
+     * kernels off sc in round 4: see gram_launch.) */
+    PipeStreams *ps = nullptr;
+    if (pipe_streams(ctx->device, &ps)) return 4;
+    const hipStream_t sc = ps->compute, sd = ps->copy;
     std::vector<hipEvent_t> done(B, nullptr);
     int rc = 0;
     std::vector<int> idx;
@@ -1608,12 +1760,27 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
                                 (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sd);
     };
     const double t_enq = now();
-    const hipError_t e = rc ? hipErrorUnknown : ship_pieces(pieces, stage, sd, rows, nthreads, issue, &t_wait, &t_scatter);
-    (void)hipStreamSynchronize(sc);
-    (void)hipStreamSynchronize(sd);
+    std::vector<double> ready_at; /* (GKM_TRACE) when each piece had arrived in its staging buffer */
+    const hipError_t e = rc ? hipErrorUnknown
+                            : ship_pieces(pieces, stage, sd, rows, nthreads, issue, &t_wait, &t_scatter, trace ? &ready_at : nullptr);
+    for (hipStream_t x : {sc, sd}) (void)hipStreamSynchronize(x);
+    if (!rc && e == hipSuccess && nparts == 1 && t_scatter > 0) { /* what the next call's block schedule goes by */
+        std::lock_guard<std::mutex> lock(g_ship.m);
+        g_ship.scatter_Bps_per_thread = total_area * 8.0 / (t_scatter * 1e-3) / nthreads;
+        const double whole = now() - t0;
+        /* the Gram kernels' share of the call: everything but the last block's copy-out (an estimate is all it takes) */
+        g_ship.cmp_per_s = ctx->h_cum_n[(size_t)n] * ctx->h_cum_n[(size_t)n] / (std::max(1.0, whole - 1.5) * 1e-3);
+    }
     if (trace)
-        fprintf(stderr, "gkmhip_gram_to_host_rows: %zu blocks, %zu pieces, setup+enqueue %.1f ms, waiting for blocks %.1f ms, host scatter %.1f ms, total %.1f ms\n",
-                B, NP, t_enq - t0, t_wait, t_scatter, now() - t0);
+        fprintf(stderr, "gkmhip_gram_to_host_rows: %zu blocks (first share %.2f of what is left, %d threads), %zu pieces, setup+enqueue %.1f ms, waiting for blocks %.1f ms, host scatter %.1f ms, total %.1f ms\n",
+                B, first_share, nthreads, NP, t_enq - t0, t_wait, t_scatter, now() - t0);
+    if (trace) {
+        fprintf(stderr, "  pieces (rows, MB, in staging at ms):");
+        for (size_t q = 0; q < ready_at.size(); q++)
+            fprintf(stderr, " [%d-%d %.0f MB @%.1f]", pieces[q].r0, pieces[q].r1,
+                    (double)pieces[q].r1 * (pieces[q].r1 - pieces[q].r0) * 8e-6, ready_at[q] - t0);
+        fprintf(stderr, "\n");
+    }
     for (auto ev : done)
         if (ev) (void)hipEventDestroy(ev);
     if (rc) return rc;
@@ -1670,17 +1837,18 @@ extern "C" int gkmhip_copy_lower_to_rows(gkmhip_ctx *ctx, const double *K, int64
     double *stage[2];
     if (acquire_staging(want, stage, 0)) return 4;
     nthreads = std::min(std::max(nthreads, 1), 16);
-    StreamPair sp;
-    HIPCHK(hipStreamCreate(&sp.a));
+    StreamSet ss;
+    if (ss.create(1)) return 4;
+    const hipStream_t sd = ss.s[0];
     std::vector<RowPiece> pieces;
     cut_pieces(0, n, want, pieces);
     auto issue = [&](size_t q) -> hipError_t {
         const RowPiece &k = pieces[q];
         return hipMemcpy2DAsync(stage[q & 1], (size_t)k.r1 * 8, K + (size_t)k.r0 * ld, (size_t)ld * 8,
-                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sp.a);
+                                (size_t)k.r1 * 8, (size_t)(k.r1 - k.r0), hipMemcpyDeviceToHost, sd);
     };
-    const hipError_t e = ship_pieces(pieces, stage, sp.a, rows, nthreads, issue, nullptr, nullptr);
-    (void)hipStreamSynchronize(sp.a);
+    const hipError_t e = ship_pieces(pieces, stage, sd, rows, nthreads, issue, nullptr, nullptr);
+    (void)hipStreamSynchronize(sd);
     if (e != hipSuccess) return set_err("copy_lower_to_rows", e, __FILE__, __LINE__);
     return 0;
 }

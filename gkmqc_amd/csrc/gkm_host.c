@@ -13,6 +13,7 @@
 #include <fcntl.h>
 #include <math.h>
 #include <stdarg.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -277,16 +278,61 @@ static int parse_fasta(const char *path, gkm_problem *p)
     return 0;
 }
 
+typedef struct {
+    const char *path;
+    gkm_problem *p;
+    int rc;
+} parse_job;
+
+static void *parse_thread(void *arg)
+{
+    parse_job *j = (parse_job *)arg;
+    j->rc = parse_fasta(j->path, j->p);
+    return NULL;
+}
+
+/* The two files are parsed at the same time (the negatives on a helper thread, into a problem of their own that is
+ * then appended): the parse is ~1 ms per 1.5 MB file and sits in front of everything else in the drop-in call. */
 gkm_problem *gkm_problem_read(const char *posfile, const char *negfile)
 {
-    gkm_problem *p = (gkm_problem *)calloc(1, sizeof *p);
-    if (!p) return NULL;
-    if (problem_reserve(p, GKM_MAX_SEQ)) { gkm_problem_free(p); return NULL; }
+    gkm_problem *p = (gkm_problem *)calloc(1, sizeof *p), *q = (gkm_problem *)calloc(1, sizeof *q);
+    if (!p || !q || problem_reserve(p, GKM_MAX_SEQ) || problem_reserve(q, GKM_MAX_SEQ)) goto fail;
     p->off[0] = 0;
-    if (parse_fasta(posfile, p)) { gkm_problem_free(p); return NULL; }
+    q->off[0] = 0;
+    init_code_table(); /* (before the helper thread exists: both parsers only read the table) */
+    parse_job neg = {negfile, q, 1};
+    pthread_t th;
+    const int threaded = pthread_create(&th, NULL, parse_thread, &neg) == 0;
+    const int rc_pos = parse_fasta(posfile, p);
+    if (threaded) pthread_join(th, NULL);
+    else parse_thread(&neg);
+    if (rc_pos || neg.rc) goto fail;
     p->n_pos = p->n;
-    if (parse_fasta(negfile, p)) { gkm_problem_free(p); return NULL; }
+    /* append the negatives: offsets shifted by the positives' bases */
+    if (p->n + q->n + 2 > p->cap) {
+        int64_t *no = (int64_t *)realloc(p->off, sizeof(int64_t) * (size_t)(p->n + q->n + 2));
+        if (!no) goto fail;
+        p->off = no;
+        p->cap = p->n + q->n + 1;
+    }
+    if (p->used + q->used > p->codes_cap) {
+        uint8_t *nc = (uint8_t *)realloc(p->codes, (size_t)(p->used + q->used + 1));
+        if (!nc) goto fail;
+        p->codes = nc;
+        p->codes_cap = p->used + q->used + 1;
+    }
+    if (q->used > 0) memcpy(p->codes + p->used, q->codes, (size_t)q->used);
+    for (int i = 1; i <= q->n; i++) p->off[p->n + i] = p->used + q->off[i];
+    p->n += q->n;
+    p->used += q->used;
+    p->invalid += q->invalid;
+    p->truncated += q->truncated;
+    gkm_problem_free(q);
     return p;
+fail:
+    gkm_problem_free(p);
+    gkm_problem_free(q);
+    return NULL;
 }
 
 void gkm_problem_free(gkm_problem *p)

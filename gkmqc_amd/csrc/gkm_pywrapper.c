@@ -81,6 +81,57 @@ static void run_on_all_devices(device_job *jobs, int ndev, void *(*phase)(void *
     }
 }
 
+/* Kept from call to call (single-device calls): the context -- with its per-launch scratch, ~0.6 GB at n = 10 000 --
+ * and the n x n device matrix.  bin/gkmqc.py makes ~20 calls of one shape per run (gkmqc.py:341-343), and creating
+ * and freeing them cost every call ~25 hipMalloc / hipFree (each waits for the device).  What the reference's
+ * "callee frees everything before it returns" (src/gkmkern_pylib.c:226-243) promises still holds for HOST memory;
+ * device memory of the last shape stays allocated until gkm_release_device_cache() or the end of the process.
+ * GKM_KEEP_DEVICE=0 frees it on return as before.  The call is not re-entrant (include/gkmkern_pylib.h), so no lock. */
+static struct {
+    gkmhip_ctx *ctx;
+    int device, L, d, rbf;
+    double gamma, c[GKM_MAX_L + 1];
+    double *dG;
+    size_t dG_elems;
+    long hits; /* calls that found both the context and a large enough matrix */
+} g_keep;
+
+long gkm_device_cache_hits(void) { return g_keep.hits; }
+
+void gkm_release_device_cache(void)
+{
+    const int caller_device = gkmhip_current_device();
+    const long hits = g_keep.hits;
+    if (g_keep.dG) gkmhip_free(g_keep.dG);
+    if (g_keep.ctx) gkmhip_destroy(g_keep.ctx);
+    memset(&g_keep, 0, sizeof g_keep);
+    g_keep.hits = hits;
+    if (caller_device >= 0) gkmhip_set_current_device(caller_device);
+}
+
+static gkmhip_ctx *kept_context(int device, int L, int d, const double *c, int rbf, double gamma)
+{
+    if (g_keep.ctx && g_keep.device == device && g_keep.L == L && g_keep.d == d && g_keep.rbf == rbf &&
+        g_keep.gamma == gamma && !memcmp(g_keep.c, c, sizeof(double) * (size_t)(d + 1)))
+        return g_keep.ctx;
+    gkm_release_device_cache();
+    g_keep.ctx = gkmhip_create(device, L, d, c, rbf, gamma);
+    if (!g_keep.ctx) return NULL;
+    g_keep.device = device; g_keep.L = L; g_keep.d = d; g_keep.rbf = rbf; g_keep.gamma = gamma;
+    memcpy(g_keep.c, c, sizeof(double) * (size_t)(d + 1));
+    return g_keep.ctx;
+}
+
+static double *kept_matrix(int device, size_t elems)
+{
+    if (g_keep.dG && g_keep.dG_elems >= elems) return g_keep.dG;
+    if (g_keep.dG) gkmhip_free(g_keep.dG);
+    g_keep.dG_elems = 0;
+    g_keep.dG = (double *)gkmhip_malloc(device, elems * sizeof(double));
+    if (g_keep.dG) g_keep.dG_elems = elems;
+    return g_keep.dG;
+}
+
 static double now_ms(void)
 {
     struct timespec ts;
@@ -231,9 +282,13 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
     /* the call must not change the caller's current HIP device (it may be a torch process) */
     caller_device = gkmhip_current_device();
     double t_created = t_parsed, t_uploaded = t_parsed, t_alloc = t_parsed;
+    const char *keep_env = getenv("GKM_KEEP_DEVICE");
+    const int keep = !(keep_env && !strcmp(keep_env, "0"));
     if (ndev == 1) {
         const int device = devs[0];
-        ctx = gkmhip_create(device, L, d, c, rbf, opts->gamma);
+        const int warm = keep && g_keep.ctx && g_keep.dG && g_keep.dG_elems >= (size_t)n * (size_t)n;
+        ctx = keep ? kept_context(device, L, d, c, rbf, opts->gamma) : gkmhip_create(device, L, d, c, rbf, opts->gamma);
+        if (warm && ctx && g_keep.dG) g_keep.hits++;
         t_created = now_ms();
         if (!ctx) {
             gkm_log(GKM_LOG_ERROR, "cannot use HIP device %d: %s", device, gkmhip_last_error());
@@ -244,7 +299,8 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
             goto done;
         }
         t_uploaded = now_ms();
-        dG = (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
+        dG = keep ? kept_matrix(device, (size_t)n * (size_t)n)
+                  : (double *)gkmhip_malloc(device, (size_t)n * (size_t)n * sizeof(double));
         t_alloc = now_ms();
         if (!dG) {
             gkm_log(GKM_LOG_ERROR, "device allocation of the %d x %d matrix failed: %s", n, n, gkmhip_last_error());
@@ -297,8 +353,12 @@ int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size)
 
 done:;
     const double t_done = now_ms();
-    if (dG) gkmhip_free(dG);
-    if (ctx) gkmhip_destroy(ctx);
+    if (ctx && ctx == g_keep.ctx) { /* kept for the next call of this shape (see g_keep) */
+        if (rc) gkm_release_device_cache(); /* ... but not after a failure: the next call starts from scratch */
+    } else {
+        if (dG) gkmhip_free(dG);
+        if (ctx) gkmhip_destroy(ctx);
+    }
     if (caller_device >= 0) gkmhip_set_current_device(caller_device);
     free(wd);
     gkm_problem_free(prob);

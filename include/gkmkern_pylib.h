@@ -32,6 +32,14 @@
  *               error during the computation itself (a failed launch or copy) can
  *               leave rows partly written; the return value is non-zero then too and
  *               the caller must discard the matrix (scripts/gkmsvm.py:90-92 does).
+ *   ownership   The callee frees all HOST memory it allocated before it returns and keeps
+ *               no pointer into the caller's memory (gkmkern_pylib.c:226-243).  DEVICE
+ *               memory of a single-GPU call -- the context with its scratch and the
+ *               n x n matrix -- is kept for the next call of the same parameters and
+ *               size (bin/gkmqc.py:341-343 makes ~20 per run; allocating and freeing it
+ *               cost every call ~25 device-wide synchronisations), until
+ *               gkm_release_device_cache(), a call with other parameters, a failed call,
+ *               or the end of the process.  GKM_KEEP_DEVICE=0 frees it on return.
  */
 #ifndef GKMKERN_PYLIB_H
 #define GKMKERN_PYLIB_H
@@ -59,6 +67,12 @@ typedef struct _gkmOpt {
 } gkmOpt;
 
 int gkm_main_pywrapper(gkmOpt *opts, double **kmat, int *kmat_size);
+
+/* Frees the device memory gkm_main_pywrapper keeps between calls (see "ownership" above); optional.
+ * No counterpart in the reference, which has no device. */
+void gkm_release_device_cache(void);
+/* calls of gkm_main_pywrapper so far that found their context and matrix already on the device */
+long gkm_device_cache_hits(void);
 
 /*
  * Host-side pieces of the same path, exported so that callers and tests can use

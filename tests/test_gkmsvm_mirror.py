@@ -211,3 +211,43 @@ def test_boundary_blocks_and_pieces_against_one_launch(built, tmp_path, monkeypa
     monkeypatch.setenv("GKM_EQUAL_BLOCKS", "1")
     got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
     assert np.array_equal(got, want)
+    monkeypatch.delenv("GKM_EQUAL_BLOCKS")
+    monkeypatch.setenv("GKM_BLOCK_FRACTIONS", "0.3,0.3,0.2,0.1")     # any cut of the rows into blocks gives the same matrix
+    got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.gpu
+def test_boundary_keeps_its_device_memory_between_calls(built, tmp_path, monkeypatch):
+    """The drop-in call keeps its context and the n x n device matrix for the next call (bin/gkmqc.py:341-343 makes ~20
+    per run): a second call of the same parameters finds them (gkm_device_cache_hits), a smaller problem reuses the
+    matrix, other parameters rebuild the context, GKM_KEEP_DEVICE=0 and gkm_release_device_cache() give the memory
+    back -- and every call returns the matrix the device layer computes in one launch."""
+    import ctypes
+    from gkmqc_amd import device, gkmsvm, synth
+    lib = device.load()
+    lib.gkm_device_cache_hits.restype = ctypes.c_long
+    lib.gkm_release_device_cache.restype = None
+    big = (str(tmp_path / "p.fa"), str(tmp_path / "n.fa"))
+    small = (str(tmp_path / "p2.fa"), str(tmp_path / "n2.fa"))
+    synth.write_problem(big[0], big[1], 700, 700, 300, None)
+    synth.write_problem(small[0], small[1], 300, 200, 300, (150, 500), seed_pos=5, seed_neg=6)
+    lib.gkm_release_device_cache()
+    h0 = lib.gkm_device_cache_hits()
+    for files, (L, k, d), hit in ((big, (11, 7, 3), 0), (big, (11, 7, 3), 1), (small, (11, 7, 3), 1),
+                                  (small, (10, 6, 3), 0), (big, (10, 6, 3), 0), (big, (10, 6, 3), 1)):
+        args = [4, L, k, d, 50, 50.0, 1.0, files[0], files[1], 4, 0]
+        want, _, _ = gkmsvm.computeGkmKernel(args, backend="device")
+        got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+        assert np.array_equal(got, want), (files, L)
+        h1 = lib.gkm_device_cache_hits()
+        assert h1 - h0 == hit, (files, L, h1 - h0)
+        h0 = h1
+    monkeypatch.setenv("GKM_KEEP_DEVICE", "0")
+    args = [4, 10, 6, 3, 50, 50.0, 1.0, big[0], big[1], 4, 0]
+    got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+    assert np.array_equal(got, gkmsvm.computeGkmKernel(args, backend="device")[0]) and lib.gkm_device_cache_hits() == h0
+    monkeypatch.delenv("GKM_KEEP_DEVICE")
+    lib.gkm_release_device_cache()
+    got, _, _ = gkmsvm.computeGkmKernel(args, backend="boundary")
+    assert lib.gkm_device_cache_hits() == h0

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 gcc -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -std=gnu11 -Iinclude -o /tmp/gkm_asan_host \
-    tools/asan_host.c gkmqc_amd/csrc/gkm_host.c -lm
+    tools/asan_host.c gkmqc_amd/csrc/gkm_host.c -lm -lpthread
 for pair in "quirks_pos.fa quirks_neg.fa" "motif_pos.fa motif_neg.fa"; do
   set -- $pair
   /tmp/gkm_asan_host tests/golden/$1 tests/golden/$2
