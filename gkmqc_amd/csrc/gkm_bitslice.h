@@ -505,8 +505,10 @@ GKM_HD HitValue resolve_hit_packed(int b, int w, int delta, int strand, uint32_t
 
 /* Origin word of a hit record.  The layout is chosen for the instruction count of the trip that consumes it, priced
  * with the issue rates measured on gfx950 (tools/valu_ops.hip, profiles/r3_valu_ops.txt: v_and / v_or / v_add / v_sub /
- * v_xor / v_lshrrev / v_lshlrev by a constant / v_bitop3 issue every ~2.2 cycles per SIMD, everything else -- v_bfe,
- * v_mad_u32_u24, v_min, v_sad, v_alignbit, v_ffbl, v_bcnt, compares, SDWA, any SGPR operand -- every ~4.2):
+ * v_xor / v_not / v_mov / v_lshrrev / v_ashrrev / v_bitop3 issue every ~2.2 cycles per SIMD; everything else -- v_lshlrev
+ * (also by a constant: 4.16, which is why the kernel doubles with v_add_u32 x, x), v_bfe, v_mad_u32_u24, v_min, v_sad,
+ * v_alignbit, v_ffbl, v_bcnt, compares, SDWA -- every ~4.2; an SGPR operand costs a stream made of nothing else 4.2 too,
+ * but nothing in a mix with VGPR-only instructions: 2.2 is what tools/issue_model.py prices it at):
  *   bits  0..3   word index w within the shift (0..W-1; a trip adds the word's offset in its group)       ms & 15
  *   bit   4      strand (0 forward, 1 reverse complement): (ms >> 2) & 4 is the byte offset of the strand's word
  *                in the interleaved column image in LDS

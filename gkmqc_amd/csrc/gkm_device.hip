@@ -214,7 +214,8 @@ struct gkmhip_ctx {
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
     DevBuf<uint32_t> lmf, sb; /* lmf: forward l-mer table, then the reverse-strand table (general kernel only) */
-    DevBuf<uint32_t> colpk;   /* 2-bit packed strands [seq][strand][pkw] (gkm_bitslice.h pk_word): the hit path's column side */
+    DevBuf<uint32_t> colpk;   /* 2-bit packed strands [seq][pkw][strand], the two strands interleaved word by word
+                               * (k_pack_strands; gkm_bitslice.h pk_word): the hit path's column side */
     int pkw = 0;
     bool have_colpk = false;
     uint32_t lm_stride = 0;
@@ -541,8 +542,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     /* LDS per wave: 3 KB hit list + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
      * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
      * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
-     * of the row lane's packed positions from global memory (5.4 KB per tile, L1 resident: the waves of a CU
-     * work on the same tile). */
+     * of the row lane's packed positions from global memory (8 KB per tile -- 128 bytes per lane, of which 84 are
+     * used -- L1 resident: the waves of a CU work on the same tile). */
     extern __shared__ uint32_t s_dyn[]; /* [wd_words] weight bytes, then [2 * pkw] column strands (forward, reverse complement) */
     /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
      * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
@@ -1553,6 +1554,35 @@ static bool runs_beside(hipStream_t busy, hipStream_t other, unsigned *d_word, u
     return beside;
 }
 
+/* A new non-blocking stream on the current device that runs beside every stream of `busy` (see PipeStreams: streams
+ * that share a hardware queue execute in order); after six candidates the last one is returned whatever it shares.
+ * *beside says which it was. */
+extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *beside)
+{
+    unsigned *d_word = nullptr, *h_word = nullptr;
+    if (hipMalloc((void **)&d_word, 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
+    if (hipHostMalloc((void **)&h_word, sizeof(unsigned), hipHostMallocPortable) != hipSuccess) {
+        (void)hipFree(d_word);
+        return nullptr;
+    }
+    std::vector<hipStream_t> rejected;
+    hipStream_t got = nullptr;
+    bool ok = false;
+    for (int attempt = 0; attempt < 6 && !ok; attempt++) {
+        hipStream_t c = nullptr;
+        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+        ok = true;
+        for (int i = 0; i < nbusy && ok; i++) ok = runs_beside((hipStream_t)busy[i], c, d_word, h_word);
+        if (ok || attempt == 5) got = c;
+        else rejected.push_back(c);
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipFree(d_word);
+    (void)hipHostFree(h_word);
+    if (beside) *beside = ok ? 1 : 0;
+    return got;
+}
+
 static int pipe_streams(int device, PipeStreams **out)
 {
     if (device < 0 || device >= 64) return set_err_msg("device ordinal out of range", 2);
@@ -1560,26 +1590,16 @@ static int pipe_streams(int device, PipeStreams **out)
     PipeStreams &P = g_pipe[device];
     *out = &P;
     if (P.compute) return 0;
-    unsigned *d_word = nullptr, *h_word = nullptr;
-    HIPCHK(hipMalloc((void **)&d_word, 2 * sizeof(unsigned)));
-    HIPCHK(hipHostMalloc((void **)&h_word, sizeof(unsigned), hipHostMallocPortable));
     HIPCHK(hipStreamCreateWithFlags(&P.compute, hipStreamNonBlocking));
-    std::vector<hipStream_t> rejected;
-    for (int attempt = 0; attempt < 6 && !P.copy_beside; attempt++) {
-        hipStream_t c = nullptr;
-        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
-        P.probes++;
-        P.copy_beside = runs_beside(P.compute, c, d_word, h_word);
-        if (P.copy_beside || attempt == 5) P.copy = c; /* (the last candidate is kept even if it shares the queue) */
-        else rejected.push_back(c);
-    }
-    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
-    (void)hipFree(d_word);
-    (void)hipHostFree(h_word);
+    void *busy[1] = {P.compute};
+    int beside = 0;
+    P.copy = (hipStream_t)gkmhip_create_stream_beside(busy, 1, &beside);
+    P.copy_beside = beside != 0;
+    P.probes = 1;
     if (!P.copy) return set_err_msg("cannot create the copy-out streams", 4);
     if (getenv("GKM_TRACE"))
-        fprintf(stderr, "gkmhip: copy-out streams of device %d after %d probe(s): the copy stream %s the compute stream\n", device,
-                P.probes, P.copy_beside ? "runs beside" : "SHARES A QUEUE WITH");
+        fprintf(stderr, "gkmhip: copy-out streams of device %d: the copy stream %s the compute stream\n", device,
+                P.copy_beside ? "runs beside" : "SHARES A QUEUE WITH");
     return 0;
 }
 

@@ -235,8 +235,16 @@ void rank_thread(Call &C, int g)
         if (!fail) MCHK(dmalloc((void **)&R.gathered, (size_t)chunks * (size_t)G * slab_elems * sizeof(double)));
         if (!fail) MCHK(dmalloc((void **)&R.d_slot, (size_t)n * sizeof(int64_t)));
         if (!fail) MCHK(dmalloc((void **)&R.sq, (size_t)n * sizeof(double)));
-        for (int i = 0; i < 2 && !fail; i++) MCHK(hipStreamCreateWithFlags(&R.sk[i], hipStreamNonBlocking));
-        if (!fail) MCHK(hipStreamCreateWithFlags(&R.sc, hipStreamNonBlocking));
+        /* the second compute stream and the transfer stream must not share a hardware queue with the first (streams
+         * on one queue execute in order: the all-gather of chunk c would wait for the kernel of chunk c+1) */
+        if (!fail) MCHK(hipStreamCreateWithFlags(&R.sk[0], hipStreamNonBlocking));
+        if (!fail) {
+            void *busy[2] = {R.sk[0], nullptr};
+            R.sk[1] = (hipStream_t)gkmhip_create_stream_beside(busy, 1, nullptr);
+            busy[1] = R.sk[1];
+            if (R.sk[1]) R.sc = (hipStream_t)gkmhip_create_stream_beside(busy, 2, nullptr);
+            if (!R.sk[1] || !R.sc) { fail = true; C.err[(size_t)g] = "cannot create the rank's streams"; }
+        }
         R.ready.assign((size_t)chunks, nullptr);
         for (auto *v : {&R.k0, &R.k1, &R.a0, &R.a1}) v->assign((size_t)chunks, nullptr);
         for (int c = 0; c < chunks && !fail; c++) {

@@ -106,22 +106,23 @@ inline int64_t packed_chunk_elems(int n, int world, int chunks)
     return pe;
 }
 
-/* Chunks per rank when the caller does not say: 64-row groups dealt round robin leave some chunk with one
- * expensive group more than the others, and every chunk slab is padded to the largest -- 21 % of the bytes with
- * 4 chunks at n = 10 000 on 8 ranks (10 groups per block), 4 % with 5.  The first of 4, 5, 3 whose padded size is
- * within 3 % of the best of the three. */
+/* Chunks per rank when the caller does not say.  A chunk more costs a launch more -- ramp and drain, ~0.7 ms beside a
+ * kernel of 75 ms / ranks -- and hides 1 / chunks more of the transfer (n = 10 000: ~0.36 GB received per rank, 1-5 ms
+ * over xGMI): chunks ~ sqrt(transfer / 0.7 ms) says 2, at most 3, for 2 to 8 ranks.  Second concern: 64-row groups
+ * dealt round robin leave some chunk with one expensive group more than the others, and every chunk slab is padded to
+ * the largest (21 % of the bytes with 4 chunks at n = 10 000 on 8 ranks, 2 % with 2).  So: 2, unless 3 pads at least
+ * 3 % less, else 4 likewise.  (Unmeasured on hardware: no round has had more than one GPU; GKM_BENCH_CHUNKS and the
+ * `chunks` argument override.) */
 inline int auto_chunks(int n, int world)
 {
     if (world <= 1) return 1;
-    const int cand[3] = {4, 5, 3};
-    double padded[3], best = 0;
-    for (int i = 0; i < 3; i++) {
-        padded[i] = (double)cand[i] * (double)packed_chunk_elems(n, world, cand[i]);
-        if (i == 0 || padded[i] < best) best = padded[i];
-    }
-    for (int i = 0; i < 3; i++)
-        if (padded[i] <= 1.03 * best) return cand[i];
-    return 4;
+    const int cand[3] = {2, 3, 4};
+    double padded[3];
+    for (int i = 0; i < 3; i++) padded[i] = (double)cand[i] * (double)packed_chunk_elems(n, world, cand[i]);
+    int best = 0;
+    for (int i = 1; i < 3; i++)
+        if (padded[i] < 0.97 * padded[best]) best = i;
+    return cand[best];
 }
 
 /* offset[a]: where matrix row a starts inside the concatenation over chunks c of the all-gathered

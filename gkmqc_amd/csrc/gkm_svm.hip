@@ -1087,7 +1087,9 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     const size_t probs_bytes = align256(sizeof(SvmProb) * (size_t)nprob);
     SvmScratch *const scr = scratch_acquire(device, probs_bytes + sizeof(double) * (size_t)n);
     if (!scr) { g_svm_err = "gkmsvm_train_batch: device scratch"; return 4; }
-    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    /* (error returns included: whatever this call enqueued may still be writing the buffer -- k_diag below -- and another
+     * solver on another stream of the device may take it from the pool next) */
+    struct Release { SvmScratch *b; hipStream_t s; ~Release() { (void)hipStreamSynchronize(s); scratch_release(b); } } release{scr, stream};
     SvmProb *const dprobs = (SvmProb *)scr->p;
     double *const diag = (double *)(scr->p + probs_bytes);
     SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(SvmProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
@@ -1119,9 +1121,12 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
 #define SMO_LAUNCH(TT, RR, TB)                                                                                  \
     if (T == TT && R == RR) {                                                                                   \
         const size_t dyn = TB == 1 ? (size_t)TT * RR * 12 : TB == 2 ? (size_t)TT * RR * 8 : 0;                  \
-        if (dyn > 0)                                                                                            \
-            SVMCHK(hipFuncSetAttribute((const void *)k_smo<TT, RR, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)dyn));                                                              \
+        if (dyn > 0 && hipFuncSetAttribute((const void *)k_smo<TT, RR, TB>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           (int)dyn) != hipSuccess) {                                           \
+            (void)hipGetLastError();                                                                            \
+            g_svm_err = "k_smo: the device refuses this launch shape (dynamic LDS)";                            \
+            return GKMSVM_RC_SHAPE_REFUSED;                                                                     \
+        }                                                                                                       \
         hipLaunchKernelGGL((k_smo<TT, RR, TB>), dim3((unsigned)nprob), dim3(TT), dyn, stream, K, ld, diag, dprobs, C, \
                            eps, max_iter);                                                                      \
     } else
@@ -1137,7 +1142,7 @@ extern "C" int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n
     SMO_LAUNCH(1024, 16, 2)
     {
         g_svm_err = "GKM_SVM_SHAPE: unsupported shape";
-        return 4;
+        return GKMSVM_RC_SHAPE_REFUSED;
     }
 #undef SMO_LAUNCH
     hipError_t e = hipGetLastError();
@@ -1173,7 +1178,9 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
     const size_t state_bytes = align256(per * (size_t)total + 64), probs_bytes = align256(sizeof(GenProb) * (size_t)nprob);
     SvmScratch *const scr = scratch_acquire(device, state_bytes + probs_bytes + sizeof(double) * (size_t)n);
     if (!scr) { g_svm_err = "gkmsvm_train_batch_general: device scratch"; return 4; }
-    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    /* (error returns included: whatever this call enqueued may still be writing the buffer -- k_diag below -- and another
+     * solver on another stream of the device may take it from the pool next) */
+    struct Release { SvmScratch *b; hipStream_t s; ~Release() { (void)hipStreamSynchronize(s); scratch_release(b); } } release{scr, stream};
     char *const scratch = scr->p;
     double *d0 = (double *)scratch;
     int *i0 = (int *)(d0 + 5 * total);
@@ -1231,7 +1238,9 @@ extern "C" int gkmsvm_decision_batch(int device, const double *K, int64_t ld, in
     if (maxtest == 0) return 0;
     SvmScratch *const scr = scratch_acquire(device, sizeof(DecProb) * (size_t)nprob);
     if (!scr) { g_svm_err = "gkmsvm_decision_batch: device scratch"; return 4; }
-    struct Release { SvmScratch *b; ~Release() { scratch_release(b); } } release{scr};
+    /* (error returns included: whatever this call enqueued may still be writing the buffer -- k_diag below -- and another
+     * solver on another stream of the device may take it from the pool next) */
+    struct Release { SvmScratch *b; hipStream_t s; ~Release() { (void)hipStreamSynchronize(s); scratch_release(b); } } release{scr, stream};
     DecProb *const dprobs = (DecProb *)scr->p;
     SVMCHK(hipMemcpyAsync(dprobs, h.data(), sizeof(DecProb) * (size_t)nprob, hipMemcpyHostToDevice, stream));
     hipLaunchKernelGGL(k_decision, dim3((unsigned)((maxtest + 127) / 128), (unsigned)nprob), dim3(128), 0, stream, K, ld,

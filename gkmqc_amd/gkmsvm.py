@@ -166,7 +166,18 @@ def _init_many_on(pairs, args, gpu, slot):
     solver_out = [threading.Event() for _ in pairs]
 
     def consumer():
-        from . import svmcv
+        # Whatever goes wrong in here -- the import included -- is recorded for the calling thread, and every event the
+        # producer may be waiting for is set on the way out: the producer never waits for a consumer that has died.
+        try:
+            from . import svmcv
+            consume(svmcv)
+        except BaseException as e:          # re-raised by the calling thread
+            errors.append(e)
+        finally:
+            for ev in solver_out:
+                ev.set()
+
+    def consume(svmcv):
         plan = None
         while True:
             item = handoff.get()
@@ -206,11 +217,23 @@ def _init_many_on(pairs, args, gpu, slot):
                 K, n_pos, n_neg = computeGkmKernel(args_gkm, gpu=gpu, resident=True, keep_context=True,
                                                    context_slot=slot)
                 gram_stream.synchronize()
-            handoff.put((s, K, n_pos, n_neg))
+            while th.is_alive():         # (a consumer that died no longer takes anything: do not block on the queue)
+                try:
+                    handoff.put((s, K, n_pos, n_neg), timeout=1.0)
+                    break
+                except queue.Full:
+                    continue
             del K
-            solver_out[s].wait()         # (the FASTA files of the next subset are read after this, a few ms of margin)
+            while not solver_out[s].wait(timeout=1.0):   # (the FASTA files of the next subset are read after this)
+                if not th.is_alive():
+                    break
     finally:
-        handoff.put(None)
+        while th.is_alive():
+            try:
+                handoff.put(None, timeout=1.0)
+                break
+            except queue.Full:
+                continue
         th.join()
         # the worker's context was kept from subset to subset; the run is over (the solver too: nothing left on the
         # device that its hipFree could wait for), so its scratch goes back before the caller allocates anything else

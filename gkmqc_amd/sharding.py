@@ -97,17 +97,19 @@ def packed_chunk_elems(n, world_size, chunks):
 
 
 def auto_chunks(n, world_size):
-    """Chunks per rank when the caller does not say (twin of gkm_shard.h auto_chunks): the first of 4, 5, 3 whose
-    padded slab size is within 3 % of the best of the three -- 64-row groups dealt round robin leave some chunk with
-    one expensive group more than the others (n = 10 000 on 8 ranks: 21 % padding with 4 chunks, 4 % with 5)."""
+    """Chunks per rank when the caller does not say (twin of gkm_shard.h auto_chunks): 2, unless 3 (or then 4) pads the
+    slabs at least 3 % less.  A chunk more costs a launch more (~0.7 ms of ramp and drain beside a kernel of 75 ms /
+    ranks) and hides 1 / chunks more of a transfer of 1-5 ms; 64-row groups dealt round robin leave some chunk with one
+    expensive group more than the others, and every slab is padded to the largest."""
     if world_size <= 1:
         return 1
-    cand = (4, 5, 3)
+    cand = (2, 3, 4)
     padded = [c * packed_chunk_elems(n, world_size, c) for c in cand]
-    for c, p in zip(cand, padded):
-        if p <= 1.03 * min(padded):
-            return c
-    return 4
+    best = 0
+    for i in (1, 2):
+        if padded[i] < 0.97 * padded[best]:
+            best = i
+    return cand[best]
 
 
 def packed_gather_offsets(n, world_size, chunks):

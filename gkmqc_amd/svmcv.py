@@ -19,6 +19,7 @@ import numpy as np
 from . import device
 
 
+SHAPE_REFUSED = 5        # GKMSVM_RC_SHAPE_REFUSED (include/gkm_svm.h)
 FAST_FOLD_SAMPLES = 16384  # k_smo: one workgroup per fold, 1024 threads x 16 samples in registers (gkm_svm.hip)
 MAX_FOLD_SAMPLES = 60000   # k_smo_general: state in global memory, also the solver with LIBSVM's shrinking
 
@@ -104,13 +105,19 @@ def train_folds(K, trains, y, C=1.0, tol=1e-3, shrinking=False, about_to_launch=
             rc = L.gkmsvm_train_batch(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx), d_idx.data_ptr(),
                                       off.ctypes.data, n0.ctypes.data, float(C), float(tol), d_alpha.data_ptr(),
                                       d_grad.data_ptr(), d_rho.data_ptr(), d_it.data_ptr(), stream)
-            if rc:   # e.g. a launch shape the device refuses (the big shapes take up to 144 KB of LDS): the general
-                     # solver needs none of that and returns the same bits without shrinking
-                logging.warning("k_smo failed (%s): solving with the general GPU solver", L.gkmsvm_last_error().decode())
+            if rc == SHAPE_REFUSED:
+                # ONLY a launch shape the device refuses (the big shapes take up to 144 KB of LDS; include/gkm_svm.h):
+                # the general solver needs none of that and returns the same bits without shrinking.  Bad arguments
+                # or a device fault are not retried -- the retry would fail too and hide the cause.
+                first = L.gkmsvm_last_error().decode()
+                logging.warning("k_smo: %s: solving with the general GPU solver", first)
                 rc = L.gkmsvm_train_batch_general(dev.index or 0, K.data_ptr(), K.stride(0), K.shape[0], len(idx),
                                                   d_idx.data_ptr(), off.ctypes.data, n0.ctypes.data, float(C), float(tol),
                                                   0, d_alpha.data_ptr(), d_grad.data_ptr(), d_rho.data_ptr(),
                                                   d_it.data_ptr(), stream)
+                if rc:
+                    raise SvmError("gkmsvm_train_batch: %s; then gkmsvm_train_batch_general: %s"
+                                   % (first, L.gkmsvm_last_error().decode()))
         if rc:
             raise SvmError("gkmsvm_train_batch: %s" % L.gkmsvm_last_error().decode())
         alpha = d_alpha.cpu().numpy()

@@ -146,7 +146,7 @@ int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
  * K[g]: device pointer ON ctxs[g]'s DEVICE to an n x ld matrix that receives K (lower triangle +
  * unit diagonal, the upper triangle too if symmetric != 0) -- the same matrix, bit for bit, as
  * gkmhip_gram_rows + gkmhip_normalize produce on one device.  chunks: slabs per rank whose transfer
- * overlaps the next slab's kernel (0 = chosen from (n, nctx): 4, 5 or 3, whichever pads the slabs least).  One host thread per device for the duration of
+ * overlaps the next slab's kernel (0 = chosen from (n, nctx): 2, or 3 / 4 where that pads the slabs 3 % less -- gkm_shard.h auto_chunks).  One host thread per device for the duration of
  * the call; blocks until every device holds the matrix.  This is what feeds the GPU-resident
  * cross-validation (include/gkm_svm.h) from an N-GPU matrix; the reference's consumer is
  * scripts/gkmsvm.py:104-122. */
@@ -175,6 +175,13 @@ int gkmhip_allgather_stats(double *out, int cap);
  * gkmhip_normalize would produce, sqnorm (device, n doubles) the self norms. */
 int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds, const int64_t *slot_of_row,
                               double *K, int64_t ld, double *sqnorm, int symmetric, void *stream);
+
+/* A new non-blocking HIP stream on the current device that is PROVEN to run beside the `nbusy` streams of `busy`
+ * (hipStream_t each): HIP maps streams onto a few hardware queues in creation order and two streams that share one
+ * execute in order -- a copy or collective stream that lands on the compute stream's queue overlaps nothing.  Each
+ * candidate is tried with a 2-ms spin kernel on the busy stream and a 4-byte copy on the candidate; after six
+ * candidates the last one is returned anyway (*beside = 0).  NULL on error.  Destroy it with hipStreamDestroy. */
+void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *beside);
 
 /* The pinned staging buffers of the copy-out calls (2 x 64 MB) are kept for the life of the
  * process; this releases them (optional). */

@@ -38,8 +38,12 @@ extern "C" {
  *   iters        out, device, nprob ints; NEGATIVE when the fold stopped at the iteration cap (10^7, LIBSVM's
  *                classic default; scikit-learn has none): that fold has not converged and must be re-solved
  *                by the caller if the reference's result is wanted
- * Returns 0 on success (work enqueued on `stream`).
+ * Returns 0 on success (work enqueued on `stream`); GKMSVM_RC_SHAPE_REFUSED when the device refuses the launch shape
+ * the largest fold needs (its dynamic LDS) -- the one failure after which gkmsvm_train_batch_general is worth trying:
+ * it keeps no state in LDS and returns the same bits without shrinking; any other value is an error of the arguments
+ * or of the device.
  */
+#define GKMSVM_RC_SHAPE_REFUSED 5
 int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob, const int *idx, const int64_t *off,
                        const int *n0, double C, double eps, double *alpha, double *grad, double *rho, int *iters,
                        void *stream);

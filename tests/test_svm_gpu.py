@@ -237,3 +237,23 @@ def test_bad_arguments_fail_loudly(built):
         svmcv.train_folds(K, [np.arange(8)], np.array([1] * 4 + [0] * 4))        # not on the GPU
     with pytest.raises(svmcv.SvmError):
         svmcv.train_folds(K.cuda(), [np.arange(4)], np.array([1] * 4 + [0] * 4))  # one class only
+
+
+def test_refused_launch_shape_falls_back_to_the_general_solver(built, monkeypatch, caplog):
+    """gkmsvm_train_batch reports a launch shape the device refuses with its own return code
+    (GKMSVM_RC_SHAPE_REFUSED, include/gkm_svm.h) and svmcv retries THAT failure -- and only that one -- with the
+    general solver: same bits as scikit-learn.  Bad arguments are not retried and raise with their own message."""
+    import logging
+    import torch
+    from gkmqc_amd import svmcv
+    K = _rbf_matrix(300, 6, seed=11)
+    trains, tests = _folds(300, 150, 3, seed=2)
+    monkeypatch.setenv("GKM_SVM_SHAPE", "2048x16")          # big enough for the folds, not a shape the library has
+    with caplog.at_level(logging.WARNING):
+        _compare_with_sklearn(K, 150, trains, tests, 1.0, 1e-3)
+    assert any("general GPU solver" in r.getMessage() for r in caplog.records)
+    monkeypatch.delenv("GKM_SVM_SHAPE")
+    y = np.concatenate((np.repeat(1, 150), np.repeat(0, 150)))
+    with pytest.raises(svmcv.SvmError) as e:                 # a fold without samples: an argument error, no retry
+        svmcv.train_folds(torch.from_numpy(K).cuda(), [trains[0], np.zeros(0, dtype=np.int64)], y, 1.0, 1e-3)
+    assert "general" not in str(e.value)
