@@ -701,6 +701,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
         auto trip = [&](auto partial_tag, int c) {
             constexpr bool PARTIAL = decltype(partial_tag)::value;
+#ifdef GKM_TRIP_PRIO /* experiment: waves inside a trip (memory round trips) issue ahead of waves in the counting loop */
+            __builtin_amdgcn_s_setprio(GKM_TRIP_PRIO);
+#endif
             /* the c records on top: lane * 4 + a scalar (kept apart from the lane term: hipcc would fuse the shift into a
              * half-rate v_lshl_add_u32 and split the reads around a negative offset) */
             const uint32_t top4 = (uint32_t)__builtin_amdgcn_readfirstlane((s_n - c) << 2);
@@ -727,8 +730,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             uint32_t pslot4 = 0u, pc0b = 0u;
             if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
                 const int from = (int)((ms >> (META_LANE_SHIFT - 2)) & 0xFCu); /* source lane * 4 */
+#ifdef GKM_BPERM_PACKED /* experiment: one permute of (slot * 4 | c0b << 16) and two full-rate VALU ops instead of two permutes */
+                const uint32_t both = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(my_slot4 | (my_c0b << 16)));
+                pslot4 = both & 0xFFFFu;
+                pc0b = both >> 16;
+#else
                 pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
                 pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
+#endif
             }
             /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
             if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
@@ -746,6 +755,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 }
                 s_n += (int)__popcll(more);
             }
+#ifdef GKM_TRIP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
         };
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
          * its first hit (lowest bit of its first non-empty word), a record with more hits is appended

@@ -398,12 +398,15 @@ def release_cached_contexts(device=None, slot=None):
 
 
 def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, want_profiles=False,
-                kernel=KERNEL_AUTO, symmetric=False, keep_context=False, context_slot=0):
+                kernel=KERNEL_AUTO, symmetric=False, keep_context=False, context_slot=0, wait=True):
     """Whole Gram matrix of `seqs` on one GPU (device memory through torch).
 
     Returns dict(K=torch fp64 [n,n] (lower triangle + unit diagonal; upper too if symmetric),
     P=int32 [n,n,d+1] or None, sqnorm=[n], kernel=name, ms=device ms of the gram kernel).
-    keep_context: use (and keep) the cached context of these parameters, see cached_context()."""
+    keep_context: use (and keep) the cached context of these parameters, see cached_context().
+    wait=False (with keep_context): return as soon as the work is enqueued on torch's current stream -- whatever the
+    caller enqueues on that stream next is ordered behind it, and the host is free meanwhile (gkmsvm.init draws the
+    cross-validation folds while the Gram kernel runs); `ms` is then None."""
     import torch
     ctx = (cached_context(kernel_type, L, k, d, M, H, gamma, device, context_slot) if keep_context
            else GramContext(kernel_type, L, k, d, M, H, gamma, device))
@@ -419,8 +422,10 @@ def gram_matrix(seqs, kernel_type, L, k, d, M=50, H=50.0, gamma=1.0, device=0, w
             sq = torch.zeros(n, dtype=torch.float64, device=dev)
             ctx.gram_rows(np.arange(n), G.data_ptr(), n, P.data_ptr() if want_profiles else None, n, False, stream)
             ctx.normalize(G.data_ptr(), n, sq.data_ptr(), symmetric, stream)
-            torch.cuda.current_stream().synchronize()   # (this stream only: others may carry unrelated work)
-            return dict(K=G, P=P, sqnorm=sq, kernel=ctx.last_kernel_name(), ms=ctx.last_kernel_ms(),
+            if not (keep_context and not wait):
+                torch.cuda.current_stream().synchronize()   # (this stream only: others may carry unrelated work)
+            return dict(K=G, P=P, sqnorm=sq, kernel=ctx.last_kernel_name(),
+                        ms=ctx.last_kernel_ms() if (wait or not keep_context) else None,
                         comparisons=ctx.last_comparisons())
     finally:
         if not keep_context:

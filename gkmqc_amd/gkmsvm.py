@@ -35,8 +35,12 @@ from . import device
 _KMAT = None  # shared with forked CV workers, like the reference's module global
 
 
-def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, keep_context=False, context_slot=0):
+def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, keep_context=False, context_slot=0,
+                     wait=True):
     """args_gkm = [kernel_type, L, k, d, M, H, gamma, pos_fa, neg_fa, n_processes, verbosity].
+
+    wait=False (resident, one GPU, keep_context): the matrix is returned as soon as its kernels are enqueued on torch's
+    current stream; whatever the caller enqueues there next (the GPU cross-validation) is ordered behind them.
 
     gpus > 1 (or a list of device ordinals): the matrix is computed on that many GPUs of the node by
     this one process (row-block sharding + RCCL all-gather behind the C ABI, include/gkm_hip.h
@@ -69,7 +73,8 @@ def computeGkmKernel(args_gkm, backend="device", gpu=0, resident=False, gpus=1, 
         del res
     else:
         K = device.gram_matrix(seqs, kernel_type, L, k, d, int(M), float(H), float(gamma), device=devices[0],
-                               keep_context=keep_context, context_slot=context_slot)["K"]
+                               keep_context=keep_context, context_slot=context_slot,
+                               wait=wait or not (resident and keep_context))["K"]
     K = torch.maximum(K, K.T)                  # scripts/gkmsvm.py:97 (lower triangle + unit diagonal, zeros above)
     if resident:
         return K, n_pos, len(seqs) - n_pos
@@ -133,8 +138,13 @@ def init(pos_fa, neg_fa, args):
     args_gkm = [args.kernel_type, args.full_word_length, args.non_gap_length, args.max_num_gaps, args.init_decay,
                 args.half_life_decay, args.rbf_gamma, pos_fa, neg_fa, args.n_processes, args.verbosity]
     logging.info("%s: building up kernel matrix", pos_fa)
-    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm, resident=getattr(args, "svm_solver", "gpu") == "gpu",
-                                              gpus=getattr(args, "gpus", 1))
+    # GPU-resident path on one GPU: the process keeps ONE context for all its subsets (bin/gkmqc.py:341-343 calls init
+    # once per subset) and does not wait for the matrix here -- the folds of the cross-validation are drawn (~10 ms of
+    # scikit-learn) while the Gram kernel runs, and the solver is enqueued behind it on the same stream.
+    on_gpu = getattr(args, "svm_solver", "gpu") == "gpu"
+    one_gpu = not isinstance(getattr(args, "gpus", 1), (list, tuple)) and int(getattr(args, "gpus", 1)) == 1
+    kmat, n_pseqs, n_nseqs = computeGkmKernel(args_gkm, resident=on_gpu, gpus=getattr(args, "gpus", 1),
+                                              keep_context=on_gpu and one_gpu, wait=not (on_gpu and one_gpu))
     args_svm = [args.regularization, args.precision, args.shrinking, args.cache_size, args.ncv, args.repeats,
                 args.fast_estimation, args.random_seeds, args.n_processes]
     logging.info("%s: svm training", pos_fa)
