@@ -514,6 +514,9 @@ constexpr int BS_CAP = BS_TRIP + 64;
 #define GKM_BS_PACKED_WAVES 6 /* several-pieces-per-lane kernels: 75-78 VGPRs */
 #endif
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill */
+#ifndef GKM_TRIP_PRIO
+#define GKM_TRIP_PRIO 3 /* wave priority (s_setprio, 0..3) inside a trip; 0 = as rounds 1-3 */
+#endif
 
 /*
  * One wavefront = 64 row segments (one per lane) x ONE column sequence.
@@ -576,6 +579,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
 
     const int lane = threadIdx.x;
+    /* (raising the priority of a NEW wave too, until its row planes are loaded, was measured: 395.4 against 388.9 ms on
+     * gkmQC's shape, nothing on config 2 -- profiles/r4_kernel_ab_trip_priority.txt) */
     /* block -> (tile, column): see BsArgs.  All of this is wave-uniform (scalar loads, SALU). */
     int lo = 0, hi = A.ntiles; /* largest tile with tile_soff[tile] <= blockIdx.x */
     while (hi - lo > 1) {
@@ -612,11 +617,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      * the source lane's pair over the permute network (ds_bpermute_b32: no LDS storage, no bank conflicts).
      * The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation granules of 1 280
      * (tools/lds_occupancy.hip): 32 instead of 24 one-wave workgroups fit a CU at 600 bp. */
-    uint32_t my_slot4 = 0u, my_c0b = 0u;
-    if (BPERM) {
-        my_slot4 = A.lane_piece[(size_t)(tile * 64 + lane) * 2];
-        my_c0b = A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1];
-    }
+    uint32_t my_both = 0u; /* row slot * 4 (< 256) | biased centre offset (< 8192) << 16 */
+    if (BPERM)
+        my_both = A.lane_piece[(size_t)(tile * 64 + lane) * 2] | (A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1] << 16);
     const uint32_t lane_tag = (uint32_t)lane << META_LANE_SHIFT, lane4 = (uint32_t)lane << 2;
     const int pkw = A.pkw;
     /* dynamic LDS: the column's two packed strands first, interleaved word by word (their address is then a constant
@@ -701,9 +704,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
         auto trip = [&](auto partial_tag, int c) {
             constexpr bool PARTIAL = decltype(partial_tag)::value;
-#ifdef GKM_TRIP_PRIO /* experiment: waves inside a trip (memory round trips) issue ahead of waves in the counting loop */
+            /* A wave inside a trip issues AHEAD of the waves that are in the counting loop (s_setprio; back to 0 at the
+             * end of the trip).  A trip is a chain of short instruction runs between LDS and memory round trips (record
+             * -> piece entry -> row words -> column words and weights -> accumulate); at equal priority each run waits
+             * its turn behind six waves of straight-line counting code, and the chain -- with the LDS list and the other
+             * lanes' hits waiting on it -- stretches.  Round 4, same-run A/B (profiles/r4_kernel_ab_trip_priority.txt):
+             * config 2 75.2 -> 72.8 ms, gkmQC's own shape 433.3 -> 396.0 ms, config 5 167.4 -> 152.7 ms; priority 1 and
+             * 3 do the same.  The total VALU work is unchanged: this is issue ORDER, not instruction count. */
             __builtin_amdgcn_s_setprio(GKM_TRIP_PRIO);
-#endif
             /* the c records on top: lane * 4 + a scalar (kept apart from the lane term: hipcc would fuse the shift into a
              * half-rate v_lshl_add_u32 and split the reads around a negative offset) */
             const uint32_t top4 = (uint32_t)__builtin_amdgcn_readfirstlane((s_n - c) << 2);
@@ -730,14 +738,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             uint32_t pslot4 = 0u, pc0b = 0u;
             if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
                 const int from = (int)((ms >> (META_LANE_SHIFT - 2)) & 0xFCu); /* source lane * 4 */
-#ifdef GKM_BPERM_PACKED /* experiment: one permute of (slot * 4 | c0b << 16) and two full-rate VALU ops instead of two permutes */
-                const uint32_t both = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)(my_slot4 | (my_c0b << 16)));
+                /* ONE permute of (slot * 4 | c0b << 16) and two full-rate VALU operations to take it apart, not two
+                 * permutes: the LDS pipe is busy two thirds of the time on gkmQC's shape (SQ_LDS_IDX_ACTIVE per CU against
+                 * the kernel's cycles, profiles/r4_pmc_peaks.json): 392.6 -> 388.6 ms (profiles/r4_kernel_ab_trip_priority.txt) */
+                const uint32_t both = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_both);
                 pslot4 = both & 0xFFFFu;
                 pc0b = both >> 16;
-#else
-                pslot4 = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_slot4);
-                pc0b = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_c0b);
-#endif
             }
             /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
             if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
@@ -755,9 +761,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 }
                 s_n += (int)__popcll(more);
             }
-#ifdef GKM_TRIP_PRIO
             __builtin_amdgcn_s_setprio(0);
-#endif
         };
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
          * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
