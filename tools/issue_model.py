@@ -30,7 +30,11 @@ FULL = {"v_xor_b32", "v_and_b32", "v_or_b32", "v_add_u32", "v_sub_u32", "v_subre
 # 4.2 in a stream made of nothing else, but NOTHING extra where VGPR-only instructions sit around it ("mix 8: 2 SGPR-operand,
 # adjacent" 2.30-2.33 against 2.30-2.32 without any), which is how the kernel uses them: two per word among twelve others.
 # C_HALF: one half-rate instruction among seven full-rate ones costs 4.0-4.1, four alternating with full-rate ones 3.8 each.
-C_FULL, C_SGPR, C_HALF = 2.2, 2.2, 4.2
+# Round 4: with the trips prioritised (s_setprio) the kernel ran FASTER than 2.2 / 4.2 allow (issue cycles / SIMD-cycles
+# 1.05-1.12), so the prices are the lower ends of what tools/valu_ops measured: 2.1 for the full-rate opcodes (v_add, v_sub,
+# v_not, v_mov, v_lshrrev: 2.07-2.11; v_bitop3 with two VGPR sources 2.27) and 3.8 for a half-rate opcode among full-rate
+# ones ("four alternating with full-rate ones 3.8 each").  The model is good to about +-5 %.
+C_FULL, C_SGPR, C_HALF = 2.1, 2.1, 3.8
 
 
 def disassemble(obj, kernel):
