@@ -1171,7 +1171,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         bs_kernel_t bs = !packed ? pick_bitslice<10, 0>(L, d) : slots == 64 ? pick_bitslice<10, 1>(L, d) : bs10;
         /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
         if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t);
+        /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
+         * kernel depend on its occupancy? */
+        const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t) + lds_pad;
         bool bperm = false;
         if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
             hipFuncAttributes fa, fb;
