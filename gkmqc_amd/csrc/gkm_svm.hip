@@ -648,6 +648,28 @@ __device__ __forceinline__ double block_max(double v, double *slots)
     return m;
 }
 
+/* block_select<true> and block_max in ONE exchange (one pair of barriers instead of two): the second selection of
+ * select_working_set needs both the best (obj_diff, position) and Gmax2 */
+__device__ __forceinline__ void block_select_min_and_max(double &v, int &k, double &mx, GenSel *slots, double *mslots)
+{
+    wave_select<true>(v, k);
+    mx = wave_max(mx);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads(); /* the previous use of the slots has been read */
+    if (lane == 0) { slots[wave].v = v; slots[wave].k = k; mslots[wave] = mx; }
+    __syncthreads();
+    double bv = INFINITY, m = mslots[0];
+    int bk = -1;
+#pragma unroll
+    for (int w = 0; w < GEN_NW; w++) {
+        if (better<true>(slots[w].v, slots[w].k, bv, bk)) { bv = slots[w].v; bk = slots[w].k; }
+        if (w) m = fmax(m, mslots[w]);
+    }
+    v = bv;
+    k = bk;
+    mx = m;
+}
+
 __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict__ K, int64_t ld,
                                                        const double *__restrict__ diag, const GenProb *probs, double C,
                                                        double eps, int max_iter, int shrinking)
@@ -774,19 +796,31 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         const int i = gi;
         Gmax = gm;
         if (i < 0) return 1;
-        q_row(i, Qi, 0, active);
+        /* Row i is gathered INSIDE the second scan (round 4; q_row() + a second pass that read Q_i back cost a write,
+         * a read and their round trip to L2 per iteration): the thread that computes Q_i[k] uses it at once and stores it
+         * for the gradient update and for Q_ij.  Same values, same order of the scan. */
+        const double *const Ki = K + (int64_t)gidx[i] * ld;
+        const int yi_ = ys[i];
         const double QDi = QD[i];
-        const double yi2 = 2.0 * (double)ys[i];
+        const double yi2 = 2.0 * (double)yi_;
         double gm2 = -INFINITY, omin = INFINITY;
         int gj = -1;
-        for (int kb = tid; kb < active; kb += GEN_T * GEN_U) { /* (each thread reads back the Q_i entries it wrote) */
-          double av[GEN_U], gv[GEN_U], qdv[GEN_U];
+        for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
+          double av[GEN_U], gv[GEN_U], qdv[GEN_U], kv[GEN_U];
           float qiv[GEN_U];
-          int yv[GEN_U];
+          int yv[GEN_U], giv[GEN_U];
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) {
               const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-              av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc]; qdv[u] = QD[kc]; qiv[u] = Qi[kc];
+              av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc]; qdv[u] = QD[kc]; giv[u] = gidx[kc];
+          }
+#pragma unroll
+          for (int u = 0; u < GEN_U; u++) kv[u] = Ki[giv[u]];
+#pragma unroll
+          for (int u = 0; u < GEN_U; u++) {
+              const int k = kb + u * GEN_T;
+              qiv[u] = (float)((double)(yi_ * yv[u]) * kv[u]); /* (Qfloat)(y_i y_k K_ik) */
+              if (k < active) Qi[k] = qiv[u];
           }
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) {
@@ -816,8 +850,8 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
           }
         }
-        const double Gmax2 = block_max(gm2, max_s);
-        block_select<true>(omin, gj, sel_s);
+        double Gmax2 = gm2;
+        block_select_min_and_max(omin, gj, Gmax2, sel_s, max_s);
         if (gm + Gmax2 < eps || gj < 0) return 1;
         out_i = i;
         out_j = gj;
@@ -907,9 +941,9 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             counter = 1; /* do shrinking next iteration */
         }
         ++iter;
-        /* the two-variable update: every thread computes the same scalars */
-        q_row(j, Qj, 0, active);
-        __syncthreads(); /* Qi[j] (written by another thread in select) and Qj are visible */
+        /* the two-variable update: every thread computes the same scalars.  (Row j is gathered inside the gradient
+         * update below, not stored and read back: round 4.) */
+        __syncthreads(); /* Qi[j] (written by another thread in select) is visible */
         const int yi = ys[i], yj = ys[j];
         const double old_ai = alpha[i], old_aj = alpha[j];
         double ai = old_ai, aj = old_aj;
@@ -950,19 +984,24 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
         }
         const double dai = ai - old_ai, daj = aj - old_aj;
+        const double *const Kj = K + (int64_t)gidx[j] * ld;
         __syncthreads(); /* everybody has read G[i], G[j], alpha[i], alpha[j] */
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
-            double gv[GEN_U];
-            float qiv[GEN_U], qjv[GEN_U];
+            double gv[GEN_U], kv[GEN_U];
+            float qiv[GEN_U];
+            int yv[GEN_U], giv[GEN_U];
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) {
                 const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-                gv[u] = G[kc]; qiv[u] = Qi[kc]; qjv[u] = Qj[kc];
+                gv[u] = G[kc]; qiv[u] = Qi[kc]; yv[u] = ys[kc]; giv[u] = gidx[kc];
             }
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) kv[u] = Kj[giv[u]];
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) {
                 const int k = kb + u * GEN_T;
-                if (k < active) G[k] = gv[u] + ((double)qiv[u] * dai + (double)qjv[u] * daj);
+                const float qj = (float)((double)(yj * yv[u]) * kv[u]); /* (Qfloat)(y_j y_k K_jk) */
+                if (k < active) G[k] = gv[u] + ((double)qiv[u] * dai + (double)qj * daj);
             }
         }
         if (tid == 0) { alpha[i] = ai; alpha[j] = aj; }
