@@ -242,3 +242,16 @@ def test_merge_of_the_two_assemblies():
     assert rc == 3 and out["value"] is None
     assert bench.merge_assemblies(None, "x", None, "y") == (None, 1)
     assert bench._strip_flag(["--gpus", "2", "--assembly", "auto", "--check", "--assembly=torch"], "--assembly") == ["--gpus", "2", "--check"]
+
+
+def test_committed_pmc_summaries_match_the_kernel_source():
+    """The line's roofline.frac comes from profiles/r*_pmc_<workload>.json, which bench.py accepts only if it was taken
+    on THIS kernel source (SHA-256 of gkm_device.hip, gkm_bitslice.h, gkm_pack.h).  An edit to those files after the last
+    tools/finalize_r4.sh run would silently turn frac into null in the driver's line: caught here."""
+    sys.path.insert(0, ROOT)
+    import bench
+    for wl in ("c2", "peaks", "c5"):
+        d, src = bench.pmc_summary(wl)
+        assert d is not None, "%s: %s -- re-run tools/finalize_r4.sh on the GPU box" % (wl, src)
+        assert d["per_launch"]["SQ_INSTS_VALU"] > 0
+        assert bench.issue_model(wl) is not None, "profiles/r*_issue_model.json is stale: python3 tools/issue_model.py --round r4"
