@@ -1058,6 +1058,10 @@ def run_rank(args, emit=None):
             c.close()
     else:
         ctx.close()
+    # descriptor 1 is the real stdout again: with `emit` the caller prints the (merged) line itself
+    sys.stdout.flush()
+    os.dup2(real_stdout.fileno(), 1)
+    real_stdout.close()
     return 3 if parity_failed else 0
 
 

@@ -102,6 +102,24 @@ def test_gpus_2_measures_the_c_abi_entry_and_falls_back_to_torch(built, how):
         assert ("injected" in d["cabi_error"]) if how == "fail" else ("killed" in d["cabi_error"])
 
 
+@pytest.mark.gpu
+def test_gpus_2_under_the_launcher_prints_its_line_on_stdout(built):
+    """The driver's own invocation for N > 1: `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`
+    (here two ranks sharing the box's one GPU).  Rank 0 runs the C-ABI child first while the other rank waits, then both
+    run the torch.distributed path; ONE line, on STDOUT (round 4's first version left descriptor 1 pointing at stderr
+    after run_rank and printed the merged line there)."""
+    env = dict(os.environ, GKM_BENCH_SHARE_GPU="1", GKM_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--gpus", "2", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    d = _one_line(r)
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "p2p" and d["assembly"].startswith("cabi")
+    assert d["also"]["torch_dist"]["transport"] == "gloo" and d["also"]["torch_dist"]["value"] > 0
+    assert d["parity"]["checked_copies"] == 2
+
+
 def test_headline_roofline_uses_only_a_matching_pmc_summary(tmp_path, monkeypatch):
     """frac comes from rocprofv3 SQ_INSTS_VALU of the committed summary; a summary taken on other kernel
     code (hash mismatch) or another workload must be refused."""
