@@ -445,6 +445,16 @@ struct BsArgs {
      * 64 consecutive doubles per store instruction; k_untile turns them into rows of G */
     double *S;
     const int64_t *tile_soff;
+    /* The ORDER of the work items (round 4): entries (column chunk, tile), chunks outermost -- all tiles take the columns
+     * [c C, (c + 1) C) before any takes the next chunk, so that a chunk's column tables (SB planes: 5-10 KB per column)
+     * are streamed from HBM once per chunk and then come from the XCD's L2 for every further tile, instead of once per
+     * tile.  Entry e covers columns [ent_j0[e], ent_j1[e]) of tile ent_tile[e] and starts at work item ent_off[e]; every
+     * entry's item count is rounded up to a multiple of 8 (padding items return at once), so that column j of a chunk
+     * has the same index mod 8 -- the same XCD under round-robin placement -- for every tile.  Inside an entry the
+     * order is what it always was: one tile, consecutive columns.  nent = 0: the plain tile-major order. */
+    int nent;
+    const int64_t *ent_off;
+    const int *ent_tile, *ent_j0, *ent_j1;
 };
 
 constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| + 1 for n <= 2047 */
@@ -582,14 +592,28 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     /* (raising the priority of a NEW wave too, until its row planes are loaded, was measured: 395.4 against 388.9 ms on
      * gkmQC's shape, nothing on config 2 -- profiles/r4_kernel_ab_trip_priority.txt) */
     /* block -> (tile, column): see BsArgs.  All of this is wave-uniform (scalar loads, SALU). */
-    int lo = 0, hi = A.ntiles; /* largest tile with tile_soff[tile] <= blockIdx.x */
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (A.tile_soff[mid] <= (int64_t)blockIdx.x) lo = mid;
-        else hi = mid;
+    int tile, j0;
+    if (A.nent > 0) { /* (chunk, tile) entries: largest e with ent_off[e] <= blockIdx.x */
+        int lo = 0, hi = A.nent;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.ent_off[mid] <= (int64_t)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        tile = A.ent_tile[lo];
+        j0 = A.ent_j0[lo] + (int)((int64_t)blockIdx.x - A.ent_off[lo]);
+        if (j0 >= A.ent_j1[lo]) return; /* padding item */
+    } else {
+        int lo = 0, hi = A.ntiles; /* largest tile with tile_soff[tile] <= blockIdx.x */
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.tile_soff[mid] <= (int64_t)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        tile = lo;
+        j0 = A.tile_cbeg[tile] + (int)((int64_t)blockIdx.x - A.tile_soff[tile]);
     }
-    const int tile = lo;
-    const int j0 = A.tile_cbeg[tile] + (int)((int64_t)blockIdx.x - A.tile_soff[tile]), j1 = j0 + 1;
+    const int j1 = j0 + 1;
     const int nrows = A.tile_nrows[tile];
     constexpr int NE = NSLOT / 64; /* row slots a lane finishes in the epilogue */
     /* A tile with at most NSLOT / 2 rows (600-bp rows: 32 per tile) keeps TWO copies of every profile, NSLOT / 2 slots
@@ -1242,6 +1266,46 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
         const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
         const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
+        /* work-item order: (column chunk, tile) entries (BsArgs) where that is free.  Measured (tools/col_chunk_sweep2.sh,
+         * profiles/r4_col_chunk_sweep.txt; kernel ms / GB read from L2 misses per launch): config 2 plain order 72.4 / 5.48,
+         * chunks of 4 096 columns 72.5 / 0.19 -- the column tables (5.3 KB per 300-bp column) of a chunk, dealt over the 8
+         * XCDs, are 2.7 MB per L2 and stay there; config 5 151.2 / 12.1 against 151.8 / 2.3; gkmQC's shape (10.3 KB per
+         * column) 384.1 / 28.7 against 385.4 / 21.9 at 4 096 (5.3 MB per L2: no reuse) and 386.4 / 4.2 at 2 560.  SMALLER
+         * chunks cost time: the 28 waves of a CU then belong to 3-5 tiles instead of 1-2 and their hit paths evict each
+         * other's packed rows from the 32 KB L1 (1 024 columns: +2 % on config 2, +6 % on the other two).  The traffic
+         * binds nothing (80 GB/s against 8 TB/s), the kernel's time is what counts: chunks of 4 096 columns where a chunk's
+         * tables fit 3 MB per XCD (config 2, config 3), the plain tile-major order everywhere else.  GKM_COL_CHUNK=<columns>
+         * overrides, 0 = plain. */
+        std::vector<int64_t> ent_off;
+        std::vector<int> ent_tile, ent_j0, ent_j1;
+        int64_t n_items = soff[(size_t)ntiles];
+        {
+            const double mean_len = ctx->h_cum_n[(size_t)n] / n + (L - 1);
+            const double col_bytes = (4.0 * (mean_len + W) + 2.0 * (mean_len / 16.0 + 1.0)) * sizeof(uint32_t);
+            long chunk = col_bytes * 4096.0 / 8.0 <= 3.0 * 1048576.0 ? 4096 : 0;
+            if (const char *cc = getenv("GKM_COL_CHUNK")) chunk = atol(cc) & ~7L;
+            if (chunk >= 8 && chunk < n) {
+                int64_t at = 0;
+                for (long c0 = 0; c0 < n; c0 += chunk)
+                    for (int t = 0; t < ntiles; t++) {
+                        const int j0 = std::max<long>(cbeg[(size_t)t], c0), j1 = (int)std::min<long>(cend[(size_t)t], c0 + chunk);
+                        if (j0 >= j1) continue;
+                        ent_off.push_back(at);
+                        ent_tile.push_back(t);
+                        ent_j0.push_back(j0);
+                        ent_j1.push_back(j1);
+                        at += (j1 - j0 + 7) & ~7;
+                    }
+                ent_off.push_back(at);
+                if (at > 0x7fffffffLL) { ent_off.clear(); ent_tile.clear(); } /* (too many items with the padding: plain order) */
+                else n_items = at;
+            }
+        }
+        const int nent = (int)ent_tile.size();
+        const size_t o_eoff = nent ? put(ent_off.data(), ent_off.size() * sizeof(int64_t)) : 0;
+        const size_t o_etile = nent ? put(ent_tile.data(), (size_t)nent * sizeof(int)) : 0;
+        const size_t o_ej0 = nent ? put(ent_j0.data(), (size_t)nent * sizeof(int)) : 0;
+        const size_t o_ej1 = nent ? put(ent_j1.data(), (size_t)nent * sizeof(int)) : 0;
         const int NS = slots;
         auto &scr = ctx->scratch[ctx->sel];
         /* (The tables and row planes on a second stream and untile on a third, so that the Gram kernels of the drop-in
@@ -1292,11 +1356,16 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.ntiles = ntiles;
         A.S = out.G ? scr.S.p : nullptr;
         A.tile_soff = (const int64_t *)(tb + o_soff);
+        A.nent = nent;
+        A.ent_off = (const int64_t *)(tb + o_eoff);
+        A.ent_tile = (const int *)(tb + o_etile);
+        A.ent_j0 = (const int *)(tb + o_ej0);
+        A.ent_j1 = (const int *)(tb + o_ej1);
         /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
          * the drain at the end of every launch costs -- nothing for one big launch, but the boundary call
          * issues 13 launches and the multi-GPU path one per chunk. */
         HIPCHK(hipEventRecord(ctx->ev0, stream));
-        hipLaunchKernelGGL(bs, dim3((unsigned)soff[(size_t)ntiles]), dim3(64), dyn_lds, stream, A);
+        hipLaunchKernelGGL(bs, dim3((unsigned)n_items), dim3(64), dyn_lds, stream, A);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(ctx->ev1, stream));
         if (out.G) {

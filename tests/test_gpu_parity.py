@@ -467,6 +467,28 @@ def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
         assert torch.equal(low["K"][nctx - 1], torch.tril(one))
 
 
+@pytest.mark.parametrize("chunk", ["8", "40", "64"])
+def test_column_chunked_work_item_order(dev, quirk_seqs, monkeypatch, chunk):
+    """The bit-sliced kernel's work items can be ordered by (column chunk, tile) entries (all tiles take a chunk of
+    columns before any takes the next: the chunk's column tables then come from the XCD's L2; taken by default at
+    n > 4 096 for ~300-bp data, so the full-size digest tests run it too).  Tiny chunks here: many entries, padding
+    items (entries are rounded up to 8 items), ragged lengths, the triangle, the full rectangle and the diagonal band --
+    the same integers and the same matrix as the plain order."""
+    import torch
+    seqs, _ = quirk_seqs
+    ragged = helpers.synth_codes(150, 150, 300, (150, 700))
+    for problem, (t, L, k, d) in ((seqs, (4, 11, 7, 3)), (ragged, (4, 12, 8, 4))):
+        monkeypatch.setenv("GKM_COL_CHUNK", "0")
+        want = dev.gram_matrix(problem, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        rows = np.arange(0, len(problem), 3)
+        want_x = dev.cross_kernel(problem, rows, t, L, k, d, kernel=dev.KERNEL_BITSLICE)
+        monkeypatch.setenv("GKM_COL_CHUNK", chunk)
+        got = dev.gram_matrix(problem, t, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+        got_x = dev.cross_kernel(problem, rows, t, L, k, d, kernel=dev.KERNEL_BITSLICE)
+        assert torch.equal(got["P"], want["P"]) and torch.equal(got["K"], want["K"]) and torch.equal(got["sqnorm"], want["sqnorm"])
+        assert torch.equal(got_x["K"], want_x["K"]) and torch.equal(got_x["sqnorm"], want_x["sqnorm"])   # full rows + diagonal band
+
+
 @pytest.mark.parametrize("kernel", ["bitslice", "direct"])
 def test_packed_row_slabs_hold_the_same_cells(dev, quirk_seqs, kernel):
     """gkmhip_gram_rows_packed (the send buffer of the multi-GPU all-gather): row rows[i] at G + row_off[i], columns
