@@ -129,6 +129,9 @@ def issue_model(workload):
         if d.get("kernel_source_sha256") == want and w:
             m = w["measured"]
             return {"source": os.path.basename(path), "issue_cycles_over_simd_cycles": m["issue_frac"],
+                    # the clock the profiled run held (GRBM_GUI_ACTIVE / 8 / kernel time) and its kernel time: the boxes of
+                    # the pool hold 2.18-2.35 GHz under this kernel, which is most of the spread between runs
+                    "profiled_run_clock_GHz": m.get("clock_GHz"), "profiled_run_kernel_ms": m.get("kernel_ms"),
                     "valu_instructions_in_trips": m["valu_in_trips"], "issue_cycles_in_trips": m["issue_cycles_in_trips"],
                     "cycles_full_rate": d["cycles_full_rate"], "cycles_sgpr_operand": d["cycles_sgpr_operand"],
                     "cycles_half_rate": d["cycles_half_rate"],
@@ -1002,7 +1005,11 @@ def run_rank(args, emit=None):
                     "kernel source + workload. kernel_ms: HIP events on the launch stream. HBM traffic is incidental.",
         }
         if n_gpus == 1 and not args.custom and args.kernel == "auto":
-            out["roofline"]["issue_model"] = issue_model(args.workload)
+            im = issue_model(args.workload)
+            if im and im.get("profiled_run_clock_GHz") and im.get("profiled_run_kernel_ms") and kern_ms > 0:
+                # same instructions, same issue cycles: the clock THIS run held, by proportion
+                im["implied_clock_GHz_this_run"] = im["profiled_run_clock_GHz"] * im["profiled_run_kernel_ms"] / kern_ms
+            out["roofline"]["issue_model"] = im
         if n_gpus > 1:
             rf = out["roofline"]
             rf.update(multi)

@@ -1763,7 +1763,11 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
     const int n = ctx->n;
     const size_t want = (size_t)64 << 20;
     double *stage[2];
+    timespec ts_a, ts_b;
+    clock_gettime(CLOCK_MONOTONIC, &ts_a);
     if (acquire_staging(want, stage, part)) return 4;
+    clock_gettime(CLOCK_MONOTONIC, &ts_b);
+    const double staging_ms = (ts_b.tv_sec - ts_a.tv_sec) * 1e3 + (ts_b.tv_nsec - ts_a.tv_nsec) * 1e-6; /* (first call: pinning 128 MB) */
     if (ctx->sq.ensure((size_t)n)) return 4;
     if (nthreads < 1) nthreads = 1;
     if (nthreads > 16) nthreads = 16;
@@ -1850,6 +1854,7 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
      * kernels off sc in round 4: see gram_launch.) */
     PipeStreams *ps = nullptr;
     if (pipe_streams(ctx->device, &ps)) return 4;
+    const double streams_ms = now() - t0; /* (first call: the streams are created and probed) */
     const hipStream_t sc = ps->compute, sd = ps->copy;
     std::vector<hipEvent_t> done(B, nullptr);
     int rc = 0;
@@ -1884,8 +1889,8 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
         g_ship.cmp_per_s = ctx->h_cum_n[(size_t)n] * ctx->h_cum_n[(size_t)n] / (std::max(1.0, whole - 1.5) * 1e-3);
     }
     if (trace)
-        fprintf(stderr, "gkmhip_gram_to_host_rows: %zu blocks (first share %.2f of what is left, %d threads), %zu pieces, setup+enqueue %.1f ms, waiting for blocks %.1f ms, host scatter %.1f ms, total %.1f ms\n",
-                B, first_share, nthreads, NP, t_enq - t0, t_wait, t_scatter, now() - t0);
+        fprintf(stderr, "gkmhip_gram_to_host_rows: %zu blocks (first share %.2f of what is left, %d threads), %zu pieces, pinned staging %.1f ms, streams %.1f ms, setup+enqueue %.1f ms (streams included), waiting for blocks %.1f ms, host scatter %.1f ms, total %.1f ms\n",
+                B, first_share, nthreads, NP, staging_ms, streams_ms, t_enq - t0, t_wait, t_scatter, now() - t0);
     if (trace) {
         fprintf(stderr, "  pieces (rows, MB, in staging at ms):");
         for (size_t q = 0; q < ready_at.size(); q++)
