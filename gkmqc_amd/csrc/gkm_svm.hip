@@ -609,9 +609,8 @@ struct GenProb {
     float *Qi, *Qj;
 };
 
-constexpr int GEN_T = 1024;
+/* threads per fold: template parameter GEN_T of k_smo_general -- 1024, or 512 for folds of at most 8 192 samples */
 constexpr int GEN_U = 8; /* positions of a thread whose loads are in flight together */
-constexpr int GEN_NW = GEN_T / 64;
 
 struct GenSel {
     double v;
@@ -619,7 +618,7 @@ struct GenSel {
 };
 
 /* block-wide best (value, position) with LIBSVM's tie rule; every thread returns the same pair */
-template <bool MINIMISE>
+template <bool MINIMISE, int GEN_NW>
 __device__ __forceinline__ void block_select(double &v, int &k, GenSel *slots)
 {
     wave_select<MINIMISE>(v, k);
@@ -635,6 +634,7 @@ __device__ __forceinline__ void block_select(double &v, int &k, GenSel *slots)
     v = bv;
     k = bk;
 }
+template <int GEN_NW>
 __device__ __forceinline__ double block_max(double v, double *slots)
 {
     v = wave_max(v);
@@ -650,6 +650,7 @@ __device__ __forceinline__ double block_max(double v, double *slots)
 
 /* block_select<true> and block_max in ONE exchange (one pair of barriers instead of two): the second selection of
  * select_working_set needs both the best (obj_diff, position) and Gmax2 */
+template <int GEN_NW>
 __device__ __forceinline__ void block_select_min_and_max(double &v, int &k, double &mx, GenSel *slots, double *mslots)
 {
     wave_select<true>(v, k);
@@ -670,10 +671,12 @@ __device__ __forceinline__ void block_select_min_and_max(double &v, int &k, doub
     mx = m;
 }
 
+template <int GEN_T>
 __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict__ K, int64_t ld,
                                                        const double *__restrict__ diag, const GenProb *probs, double C,
                                                        double eps, int max_iter, int shrinking)
 {
+    constexpr int GEN_NW = GEN_T / 64;
     __shared__ GenSel sel_s[GEN_NW];
     __shared__ double max_s[GEN_NW];
     __shared__ double chunk[GEN_T];
@@ -725,6 +728,12 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         }
     };
 
+#ifdef SVM_PROF
+    long long gp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, g0 = clock64(), g1;
+#define GPROF(n) g1 = clock64(); gp[n] += g1 - g0; g0 = g1;
+#else
+#define GPROF(n)
+#endif
     int active = l;
     /* Solver::reconstruct_gradient */
     auto reconstruct = [&]() {
@@ -768,7 +777,6 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     };
 
     /* Solver::select_working_set; 0 = pair found.  Leaves Q_i[0..active) in Qi. */
-    double Gmax = 0.0;
     auto select = [&](int &out_i, int &out_j) -> int {
         double gm = -INFINITY;
         int gi = -1;
@@ -792,9 +800,10 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                 }
             }
         }
-        block_select<false>(gm, gi, sel_s);
+        GPROF(0)
+        block_select<false, GEN_NW>(gm, gi, sel_s);
+        GPROF(1)
         const int i = gi;
-        Gmax = gm;
         if (i < 0) return 1;
         /* Row i is gathered INSIDE the second scan (round 4; q_row() + a second pass that read Q_i back cost a write,
          * a read and their round trip to L2 per iteration): the thread that computes Q_i[k] uses it at once and stores it
@@ -850,8 +859,10 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
           }
         }
+        GPROF(2)
         double Gmax2 = gm2;
-        block_select_min_and_max(omin, gj, Gmax2, sel_s, max_s);
+        block_select_min_and_max<GEN_NW>(omin, gj, Gmax2, sel_s, max_s);
+        GPROF(3)
         if (gm + Gmax2 < eps || gj < 0) return 1;
         out_i = i;
         out_j = gj;
@@ -872,7 +883,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                 if (!is_lower(a) && g >= g1) g1 = g;
             }
         }
-        const double Gmax1 = block_max(g1, max_s), Gmax2 = block_max(g2, max_s);
+        const double Gmax1 = block_max<GEN_NW>(g1, max_s), Gmax2 = block_max<GEN_NW>(g2, max_s);
         if (!unshrink && Gmax1 + Gmax2 <= eps * 10) {
             unshrink = true;
             reconstruct();
@@ -986,6 +997,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         const double dai = ai - old_ai, daj = aj - old_aj;
         const double *const Kj = K + (int64_t)gidx[j] * ld;
         __syncthreads(); /* everybody has read G[i], G[j], alpha[i], alpha[j] */
+        GPROF(4)
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
             double gv[GEN_U], kv[GEN_U];
             float qiv[GEN_U];
@@ -1005,6 +1017,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
         }
         if (tid == 0) { alpha[i] = ai; alpha[j] = aj; }
+        GPROF(5)
         if (shrinking) { /* G_bar only matters to reconstruct_gradient */
             const bool ui = is_upper(old_ai), uj = is_upper(old_aj);
             if (ui != is_upper(ai)) {
@@ -1019,8 +1032,16 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
         }
         __syncthreads();
+        GPROF(6)
     }
 
+#ifdef SVM_PROF
+    if (tid == 0 && blockIdx.x == 0 && iter != 0) {
+        const int it = iter < 0 ? -iter : iter;
+        printf("k_smo_general<%d> iters %d cycles/iter: scan1 %lld select1 %lld gather_i+scan2 %lld select2 %lld scalars %lld gather_j+update %lld rest %lld\n",
+               GEN_T, it, gp[0] / it, gp[1] / it, gp[2] / it, gp[3] / it, gp[4] / it, gp[5] / it, gp[6] / it);
+    }
+#endif
     /* Solver::calculate_rho over all l positions (active == l here), the free samples summed in position order */
     __syncthreads();
     int nr_free = 0;
@@ -1051,8 +1072,8 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
         }
     }
-    ub = -block_max(-ub, max_s);
-    lb = block_max(lb, max_s);
+    ub = -block_max<GEN_NW>(-ub, max_s);
+    lb = block_max<GEN_NW>(lb, max_s);
     if (tid == 0) {
         *p.rho = nr_free > 0 ? sum_free / nr_free : (ub + lb) / 2;
         *p.iters = iter;
@@ -1244,10 +1265,19 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         int max_iter = 10000000;
         if (const char *mi = getenv("GKM_SVM_MAX_ITER")) if (atoi(mi) > 0) max_iter = atoi(mi);
         const size_t dyn = ((size_t)maxl + 15) & ~(size_t)15;
-        e = hipFuncSetAttribute((const void *)k_smo_general, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        /* 512 threads for folds of at most 8 192 samples (GKM_SVM_GEN_T=512|1024 overrides): half the waves per barrier
+         * and per block-wide selection, sixteen positions per thread */
+        int gt = maxl <= 8192 ? 512 : 1024;
+        if (const char *g = getenv("GKM_SVM_GEN_T")) gt = atoi(g) == 512 ? 512 : 1024;
+        const void *fn = gt == 512 ? (const void *)k_smo_general<512> : (const void *)k_smo_general<1024>;
+        e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_smo_general, dim3((unsigned)nprob), dim3(GEN_T), dyn, stream, K, ld, diag, dprobs, C, eps,
-                               max_iter, shrinking ? 1 : 0);
+            if (gt == 512)
+                hipLaunchKernelGGL(k_smo_general<512>, dim3((unsigned)nprob), dim3(512), dyn, stream, K, ld, diag, dprobs, C, eps,
+                                   max_iter, shrinking ? 1 : 0);
+            else
+                hipLaunchKernelGGL(k_smo_general<1024>, dim3((unsigned)nprob), dim3(1024), dyn, stream, K, ld, diag, dprobs, C,
+                                   eps, max_iter, shrinking ? 1 : 0);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
