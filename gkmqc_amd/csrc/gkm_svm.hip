@@ -611,6 +611,20 @@ struct GenProb {
 
 /* threads per fold: template parameter GEN_T of k_smo_general -- 1024, or 512 for folds of at most 8 192 samples */
 constexpr int GEN_U = 8; /* positions of a thread whose loads are in flight together */
+/* LDS_STATE (round 4): for folds of at most GEN_LDS_L samples the state the three scans of an iteration read -- G, Q_i,
+ * the matrix index and one byte of "label, alpha at 0, alpha at C" per position -- lives in LDS (18 bytes per sample
+ * + the shrinking flag), not in L2: a scan then costs LDS reads and ONE dependent trip to the matrix row.  alpha itself
+ * (read at i and j only), QD, G_bar and the rest stay in global memory. */
+constexpr int GEN_LDS_L = 8192;
+#ifndef GEN_U_LDS
+#define GEN_U_LDS 16 /* 512 threads x 16 = every position of such a fold in ONE round of loads */
+#endif
+constexpr unsigned ST_LO = 1u, ST_UP = 2u, ST_POS = 4u;
+template <bool B, class T>
+__device__ __forceinline__ T *pick(T *a, T *b)
+{
+    if constexpr (B) return a; else return b;
+}
 
 struct GenSel {
     double v;
@@ -618,21 +632,23 @@ struct GenSel {
 };
 
 /* block-wide best (value, position) with LIBSVM's tie rule; every thread returns the same pair */
+/* ONE barrier and a DPP row selection over the wave winners (k_smo's way; round 4 -- before: two barriers and a scalar scan
+ * of the slots in every thread, 7-14 k cycles per selection, profiles/r4_svm_general_phases.txt).  `slots` must not be
+ * the array of the previous selection: every call site has its own, so that whoever still reads the previous one is at
+ * least one barrier behind. */
 template <bool MINIMISE, int GEN_NW>
 __device__ __forceinline__ void block_select(double &v, int &k, GenSel *slots)
 {
+    static_assert(GEN_NW <= 16 && (GEN_NW & (GEN_NW - 1)) == 0, "the wave winners fit one DPP row of 16 lanes");
     wave_select<MINIMISE>(v, k);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads(); /* the previous use of `slots` has been read */
     if (lane == 0) { slots[wave].v = v; slots[wave].k = k; }
     __syncthreads();
-    double bv = MINIMISE ? INFINITY : -INFINITY;
-    int bk = -1;
-#pragma unroll
-    for (int w = 0; w < GEN_NW; w++)
-        if (better<MINIMISE>(slots[w].v, slots[w].k, bv, bk)) { bv = slots[w].v; bk = slots[w].k; }
-    v = bv;
-    k = bk;
+    int wk = slots[lane & (GEN_NW - 1)].k;
+    double wv = wk >= 0 ? slots[lane & (GEN_NW - 1)].v : (MINIMISE ? INFINITY : -INFINITY);
+    (void)row_select<MINIMISE>(wv, wk);
+    v = wv;
+    k = wk;
 }
 template <int GEN_NW>
 __device__ __forceinline__ double block_max(double v, double *slots)
@@ -656,38 +672,47 @@ __device__ __forceinline__ void block_select_min_and_max(double &v, int &k, doub
     wave_select<true>(v, k);
     mx = wave_max(mx);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __syncthreads(); /* the previous use of the slots has been read */
     if (lane == 0) { slots[wave].v = v; slots[wave].k = k; mslots[wave] = mx; }
     __syncthreads();
-    double bv = INFINITY, m = mslots[0];
-    int bk = -1;
-#pragma unroll
-    for (int w = 0; w < GEN_NW; w++) {
-        if (better<true>(slots[w].v, slots[w].k, bv, bk)) { bv = slots[w].v; bk = slots[w].k; }
-        if (w) m = fmax(m, mslots[w]);
-    }
-    v = bv;
-    k = bk;
-    mx = m;
+    int wk = slots[lane & (GEN_NW - 1)].k;
+    double wv = wk >= 0 ? slots[lane & (GEN_NW - 1)].v : INFINITY;
+    (void)row_select<true>(wv, wk);
+    v = wv;
+    k = wk;
+    mx = row_max(mslots[lane & (GEN_NW - 1)]);
 }
 
-template <int GEN_T>
+template <int GEN_T, bool LDS_STATE>
 __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict__ K, int64_t ld,
                                                        const double *__restrict__ diag, const GenProb *probs, double C,
-                                                       double eps, int max_iter, int shrinking)
+                                                       double eps, int max_iter, int shrinking, int cap)
 {
     constexpr int GEN_NW = GEN_T / 64;
-    __shared__ GenSel sel_s[GEN_NW];
-    __shared__ double max_s[GEN_NW];
+    constexpr int GEN_U = LDS_STATE ? GEN_U_LDS : ::GEN_U;
+    __shared__ GenSel sel_s[GEN_NW], selb_s[GEN_NW]; /* first / second selection: one array each (see block_select) */
+    __shared__ double max_s[GEN_NW], maxb_s[GEN_NW];
     __shared__ double chunk[GEN_T];
     __shared__ int chunk_g[GEN_T], chunk_y[GEN_T];
     __shared__ int misc[4];
-    extern __shared__ unsigned char flag_s[]; /* l bytes: be_shrunk() of every active position */
+    /* dynamic LDS, `cap` = the largest fold of the launch rounded up to 16: cap bytes of be_shrunk() flags of the active
+     * positions; with LDS_STATE then cap state bytes, cap doubles G, cap floats Q_i, cap ints matrix index */
+    extern __shared__ __attribute__((aligned(16))) unsigned char flag_s[];
+    unsigned char *const st_s = flag_s + cap;
     const GenProb p = probs[blockIdx.x];
     const int tid = threadIdx.x, l = p.l;
-    int *const gidx = p.gidx, *const ys = p.ys, *const aset = p.aset;
-    double *const alpha = p.alpha, *const G = p.G, *const Gbar = p.Gbar, *const QD = p.QD;
-    float *const Qi = p.Qi, *const Qj = p.Qj;
+    int *const gidx = pick<LDS_STATE>((int *)(flag_s + (size_t)14 * cap), p.gidx), *const ys = p.ys, *const aset = p.aset;
+    double *const alpha = p.alpha, *const G = pick<LDS_STATE>((double *)(flag_s + (size_t)2 * cap), p.G), *const Gbar = p.Gbar,
+                  *const QD = p.QD;
+    float *const Qi = pick<LDS_STATE>((float *)(flag_s + (size_t)10 * cap), p.Qi), *const Qj = p.Qj;
+
+    auto is_upper = [&](double a) { return a >= C; };
+    auto is_lower = [&](double a) { return a <= 0.0; };
+    auto encode = [&](double a, int y) -> unsigned { return (a <= 0.0 ? ST_LO : 0u) | (a >= C ? ST_UP : 0u) | (y > 0 ? ST_POS : 0u); };
+    /* what the scans need of position k: is_lower_bound, is_upper_bound, the label */
+    auto st_load = [&](int k) -> unsigned {
+        if constexpr (LDS_STATE) return st_s[k];
+        else return encode(alpha[k], ys[k]);
+    };
 
     for (int k = tid; k < l; k += GEN_T) {
         const int g = p.idx[k];
@@ -698,11 +723,10 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         G[k] = -1.0; /* p = -1 */
         Gbar[k] = 0.0;
         QD[k] = diag[g];
+        if constexpr (LDS_STATE) st_s[k] = (unsigned char)encode(0.0, k < p.n0 ? 1 : -1);
     }
     __syncthreads();
 
-    auto is_upper = [&](double a) { return a >= C; };
-    auto is_lower = [&](double a) { return a <= 0.0; };
     /* Q_t[k] = (Qfloat)(y_t y_k K_tk) for k in [k0, k1) */
     auto q_row = [&](int t, float *out, int k0, int k1) {
         const double *Kt = K + (int64_t)gidx[t] * ld;
@@ -781,23 +805,21 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         double gm = -INFINITY;
         int gi = -1;
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
-            double av[GEN_U], gv[GEN_U];
-            int yv[GEN_U];
+            double gv[GEN_U];
+            unsigned sv[GEN_U];
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) {
                 const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-                av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc];
+                gv[u] = G[kc]; sv[u] = st_load(kc);
             }
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) { /* ascending k inside the thread: ">=" keeps LIBSVM's last-of-equals */
                 const int k = kb + u * GEN_T;
-                if (k >= active) break;
-                const double a = av[u], g = gv[u];
-                if (yv[u] == +1) {
-                    if (!is_upper(a) && -g >= gm) { gm = -g; gi = k; }
-                } else {
-                    if (!is_lower(a) && g >= gm) { gm = g; gi = k; }
-                }
+                if (k >= active) continue;
+                /* y = +1: not at C, -G;  y = -1: not at 0, +G -- one comparison for both labels */
+                const bool pos = (sv[u] & ST_POS) != 0;
+                const double val = pos ? -gv[u] : gv[u];
+                if (!(sv[u] & (pos ? ST_UP : ST_LO)) && val >= gm) { gm = val; gi = k; }
             }
         }
         GPROF(0)
@@ -811,57 +833,53 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         const double *const Ki = K + (int64_t)gidx[i] * ld;
         const int yi_ = ys[i];
         const double QDi = QD[i];
-        const double yi2 = 2.0 * (double)yi_;
         double gm2 = -INFINITY, omin = INFINITY;
         int gj = -1;
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
-          double av[GEN_U], gv[GEN_U], qdv[GEN_U], kv[GEN_U];
+          double gv[GEN_U], qdv[GEN_U], kv[GEN_U];
           float qiv[GEN_U];
-          int yv[GEN_U], giv[GEN_U];
+          unsigned sv[GEN_U];
+          int giv[GEN_U];
 #pragma unroll
-          for (int u = 0; u < GEN_U; u++) {
+          for (int u = 0; u < GEN_U; u++) { /* the matrix index first: the trip to row i hangs on it */
               const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-              av[u] = alpha[kc]; gv[u] = G[kc]; yv[u] = ys[kc]; qdv[u] = QD[kc]; giv[u] = gidx[kc];
+              giv[u] = gidx[kc];
           }
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) kv[u] = Ki[giv[u]];
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) {
-              const int k = kb + u * GEN_T;
-              qiv[u] = (float)((double)(yi_ * yv[u]) * kv[u]); /* (Qfloat)(y_i y_k K_ik) */
-              if (k < active) Qi[k] = qiv[u];
+              const int k = kb + u * GEN_T, kc = k < active ? k : kb;
+              gv[u] = G[kc]; sv[u] = st_load(kc); qdv[u] = QD[kc];
           }
+          /* Branch-free, one IEEE division per position (k_smo's form of the same arithmetic; a wave holds both labels,
+           * and LIBSVM's two branches -- a double division each -- ran one after the other):
+           *   Q_ik = (Qfloat)(y_i y_k K_ik) = +-(Qfloat)K_ik (rounding is symmetric);
+           *   with s = y_k: gm + G / gm - G is gm + sG, and -G >= Gmax2 / G >= Gmax2 is sG >= Gmax2;
+           *   2 y_i Q_ik = s 2 (Qfloat)K_ik exactly, so QD_i + QD_k -/+ 2 y_i Q_ik is (QD_i + QD_k) - 2 (Qfloat)K_ik for
+           *   both labels (a - b and a + (-b) are the same IEEE operation);
+           *   the quotient by quad_coef > 0 ? quad_coef : TAU is LIBSVM's either way. */
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) {
-            const int k = kb + u * GEN_T;
-            if (k >= active) break;
-            const double a = av[u], g = gv[u];
-            if (yv[u] == +1) {
-                if (!is_lower(a)) {
-                    const double grad_diff = gm + g;
-                    if (g >= gm2) gm2 = g;
-                    if (grad_diff > 0) {
-                        const double quad_coef = QDi + qdv[u] - yi2 * (double)qiv[u];
-                        const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
-                        if (obj_diff <= omin) { gj = k; omin = obj_diff; }
-                    }
-                }
-            } else {
-                if (!is_upper(a)) {
-                    const double grad_diff = gm - g;
-                    if (-g >= gm2) gm2 = -g;
-                    if (grad_diff > 0) {
-                        const double quad_coef = QDi + qdv[u] + yi2 * (double)qiv[u];
-                        const double obj_diff = quad_coef > 0 ? -(grad_diff * grad_diff) / quad_coef : -(grad_diff * grad_diff) / SVM_TAU;
-                        if (obj_diff <= omin) { gj = k; omin = obj_diff; }
-                    }
-                }
-            }
+              const int k = kb + u * GEN_T;
+              const bool pos = (sv[u] & ST_POS) != 0;
+              const float kf = (float)kv[u];
+              qiv[u] = (yi_ > 0) == pos ? kf : -kf;
+              if (k < active) Qi[k] = qiv[u];
+              const bool in_low = (k < active) & !(sv[u] & (pos ? ST_LO : ST_UP));
+              const double gs = pos ? gv[u] : -gv[u];
+              gm2 = (in_low & (gs >= gm2)) ? gs : gm2;
+              const double grad_diff = gm + gs;
+              const double quad_coef = (QDi + qdv[u]) - 2.0 * (double)kf;
+              const double obj_diff = -(grad_diff * grad_diff) / (quad_coef > 0 ? quad_coef : SVM_TAU);
+              const bool take = in_low & (grad_diff > 0) & (obj_diff <= omin);
+              omin = take ? obj_diff : omin;
+              gj = take ? k : gj;
           }
         }
         GPROF(2)
         double Gmax2 = gm2;
-        block_select_min_and_max<GEN_NW>(omin, gj, Gmax2, sel_s, max_s);
+        block_select_min_and_max<GEN_NW>(omin, gj, Gmax2, selb_s, maxb_s);
         GPROF(3)
         if (gm + Gmax2 < eps || gj < 0) return 1;
         out_i = i;
@@ -925,6 +943,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             { const int t = ys[a]; ys[a] = ys[b]; ys[b] = t; }
             { const int t = aset[a]; aset[a] = aset[b]; aset[b] = t; }
             { const double t = alpha[a]; alpha[a] = alpha[b]; alpha[b] = t; }
+            if constexpr (LDS_STATE) { const unsigned char t = st_s[a]; st_s[a] = st_s[b]; st_s[b] = t; }
             { const double t = G[a]; G[a] = G[b]; G[b] = t; }
             { const double t = Gbar[a]; Gbar[a] = Gbar[b]; Gbar[b] = t; }
             { const double t = QD[a]; QD[a] = QD[b]; QD[b] = t; }
@@ -953,14 +972,26 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         }
         ++iter;
         /* the two-variable update: every thread computes the same scalars.  (Row j is gathered inside the gradient
-         * update below, not stored and read back: round 4.) */
-        __syncthreads(); /* Qi[j] (written by another thread in select) is visible */
+         * update below, not stored and read back: round 4.)  Qi[j], written by another thread in select(), is visible:
+         * the barrier of the second selection came after every thread's writes. */
         const int yi = ys[i], yj = ys[j];
-        const double old_ai = alpha[i], old_aj = alpha[j];
+        const double old_ai = alpha[i], old_aj = alpha[j], QD_i = QD[i], QD_j = QD[j];
+        const double *const Kj = K + (int64_t)gidx[j] * ld;
+        /* LDS_STATE: one round of loads covers the fold, so the trip to row j starts HERE, under the scalar update (after
+         * the loads of the scalars: loads return in order) */
+        static_assert(!LDS_STATE || GEN_T * GEN_U >= GEN_LDS_L, "one round of loads covers an LDS-resident fold");
+        double kvj[LDS_STATE ? GEN_U : 1];
+        if constexpr (LDS_STATE) {
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = tid + u * GEN_T;
+                kvj[u] = Kj[gidx[k < active ? k : 0]];
+            }
+        }
         double ai = old_ai, aj = old_aj;
         const double Qij = (double)Qi[j];
         if (yi != yj) {
-            double quad_coef = QD[i] + QD[j] + 2 * Qij;
+            double quad_coef = QD_i + QD_j + 2 * Qij;
             if (quad_coef <= 0) quad_coef = SVM_TAU;
             const double delta = (-G[i] - G[j]) / quad_coef;
             const double diff = ai - aj;
@@ -977,7 +1008,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                 if (aj > C) { aj = C; ai = C + diff; }
             }
         } else {
-            double quad_coef = QD[i] + QD[j] - 2 * Qij;
+            double quad_coef = QD_i + QD_j - 2 * Qij;
             if (quad_coef <= 0) quad_coef = SVM_TAU;
             const double delta = (G[i] - G[j]) / quad_coef;
             const double sum = ai + aj;
@@ -995,9 +1026,18 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             }
         }
         const double dai = ai - old_ai, daj = aj - old_aj;
-        const double *const Kj = K + (int64_t)gidx[j] * ld;
         __syncthreads(); /* everybody has read G[i], G[j], alpha[i], alpha[j] */
         GPROF(4)
+        if constexpr (LDS_STATE) {
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = tid + u * GEN_T;
+                if (k < active) {
+                    const float qj = (float)((double)(yj * ((st_s[k] & ST_POS) ? 1 : -1)) * kvj[u]); /* (Qfloat)(y_j y_k K_jk) */
+                    G[k] = G[k] + ((double)Qi[k] * dai + (double)qj * daj);
+                }
+            }
+        } else
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
             double gv[GEN_U], kv[GEN_U];
             float qiv[GEN_U];
@@ -1005,10 +1045,17 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) {
                 const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-                gv[u] = G[kc]; qiv[u] = Qi[kc]; yv[u] = ys[kc]; giv[u] = gidx[kc];
+                giv[u] = gidx[kc];
             }
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) kv[u] = Kj[giv[u]];
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = kb + u * GEN_T, kc = k < active ? k : kb;
+                gv[u] = G[kc]; qiv[u] = Qi[kc];
+                if constexpr (LDS_STATE) yv[u] = (st_s[kc] & ST_POS) ? 1 : -1;
+                else yv[u] = ys[kc];
+            }
 #pragma unroll
             for (int u = 0; u < GEN_U; u++) {
                 const int k = kb + u * GEN_T;
@@ -1016,7 +1063,15 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                 if (k < active) G[k] = gv[u] + ((double)qiv[u] * dai + (double)qj * daj);
             }
         }
-        if (tid == 0) { alpha[i] = ai; alpha[j] = aj; }
+        /* written by the threads that scan these positions (k = tid + u GEN_T everywhere): see the end of the loop */
+        if (tid == (i & (GEN_T - 1))) {
+            alpha[i] = ai;
+            if constexpr (LDS_STATE) st_s[i] = (unsigned char)encode(ai, yi);
+        }
+        if (tid == (j & (GEN_T - 1))) {
+            alpha[j] = aj;
+            if constexpr (LDS_STATE) st_s[j] = (unsigned char)encode(aj, yj);
+        }
         GPROF(5)
         if (shrinking) { /* G_bar only matters to reconstruct_gradient */
             const bool ui = is_upper(old_ai), uj = is_upper(old_aj);
@@ -1031,15 +1086,18 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                 for (int k = tid; k < l; k += GEN_T) Gbar[k] = uj ? Gbar[k] - C * (double)Qj[k] : Gbar[k] + C * (double)Qj[k];
             }
         }
-        __syncthreads();
+        /* Without shrinking no barrier is needed here: every scan and the gradient update deal position k to thread k mod GEN_T,
+         * so the first scan of the next iteration reads only what this thread wrote (G, the state byte, alpha); what all
+         * threads read of other positions (alpha, G, QD at i and j; Qi[j]) is read after the next selections' barriers. */
+        if (shrinking) __syncthreads();
         GPROF(6)
     }
 
 #ifdef SVM_PROF
     if (tid == 0 && blockIdx.x == 0 && iter != 0) {
         const int it = iter < 0 ? -iter : iter;
-        printf("k_smo_general<%d> iters %d cycles/iter: scan1 %lld select1 %lld gather_i+scan2 %lld select2 %lld scalars %lld gather_j+update %lld rest %lld\n",
-               GEN_T, it, gp[0] / it, gp[1] / it, gp[2] / it, gp[3] / it, gp[4] / it, gp[5] / it, gp[6] / it);
+        printf("k_smo_general<%d,%d> iters %d cycles/iter: scan1 %lld select1 %lld gather_i+scan2 %lld select2 %lld scalars %lld gather_j+update %lld rest %lld\n",
+               GEN_T, (int)LDS_STATE, it, gp[0] / it, gp[1] / it, gp[2] / it, gp[3] / it, gp[4] / it, gp[5] / it, gp[6] / it);
     }
 #endif
     /* Solver::calculate_rho over all l positions (active == l here), the free samples summed in position order */
@@ -1264,20 +1322,28 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         hipLaunchKernelGGL(k_diag, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, K, ld, n, diag);
         int max_iter = 10000000;
         if (const char *mi = getenv("GKM_SVM_MAX_ITER")) if (atoi(mi) > 0) max_iter = atoi(mi);
-        const size_t dyn = ((size_t)maxl + 15) & ~(size_t)15;
+        const int cap = (int)(((size_t)maxl + 15) & ~(size_t)15);
         /* 512 threads for folds of at most 8 192 samples (GKM_SVM_GEN_T=512|1024 overrides): half the waves per barrier
-         * and per block-wide selection, sixteen positions per thread */
-        int gt = maxl <= 8192 ? 512 : 1024;
+         * and per block-wide selection, sixteen positions per thread -- and the scanned state in LDS (GKM_SVM_GEN_LDS=0:
+         * in global memory as for larger folds, for timing) */
+        int gt = maxl <= GEN_LDS_L ? 512 : 1024;
         if (const char *g = getenv("GKM_SVM_GEN_T")) gt = atoi(g) == 512 ? 512 : 1024;
-        const void *fn = gt == 512 ? (const void *)k_smo_general<512> : (const void *)k_smo_general<1024>;
+        bool lds_state = gt == 512 && maxl <= GEN_LDS_L;
+        if (const char *g = getenv("GKM_SVM_GEN_LDS")) lds_state = lds_state && atoi(g) != 0;
+        const size_t dyn = lds_state ? (size_t)18 * cap : (size_t)cap;
+        const void *fn = lds_state ? (const void *)k_smo_general<512, true>
+                         : gt == 512 ? (const void *)k_smo_general<512, false> : (const void *)k_smo_general<1024, false>;
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
         if (e == hipSuccess) {
-            if (gt == 512)
-                hipLaunchKernelGGL(k_smo_general<512>, dim3((unsigned)nprob), dim3(512), dyn, stream, K, ld, diag, dprobs, C, eps,
-                                   max_iter, shrinking ? 1 : 0);
+            if (lds_state)
+                hipLaunchKernelGGL((k_smo_general<512, true>), dim3((unsigned)nprob), dim3(512), dyn, stream, K, ld, diag, dprobs, C,
+                                   eps, max_iter, shrinking ? 1 : 0, cap);
+            else if (gt == 512)
+                hipLaunchKernelGGL((k_smo_general<512, false>), dim3((unsigned)nprob), dim3(512), dyn, stream, K, ld, diag, dprobs, C,
+                                   eps, max_iter, shrinking ? 1 : 0, cap);
             else
-                hipLaunchKernelGGL(k_smo_general<1024>, dim3((unsigned)nprob), dim3(1024), dyn, stream, K, ld, diag, dprobs, C,
-                                   eps, max_iter, shrinking ? 1 : 0);
+                hipLaunchKernelGGL((k_smo_general<1024, false>), dim3((unsigned)nprob), dim3(1024), dyn, stream, K, ld, diag, dprobs,
+                                   C, eps, max_iter, shrinking ? 1 : 0, cap);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipStreamSynchronize(stream);
