@@ -620,8 +620,17 @@ constexpr int GEN_LDS_L = 8192;
 #define GEN_U_LDS 16 /* 512 threads x 16 = every position of such a fold in ONE round of loads */
 #endif
 constexpr unsigned ST_LO = 1u, ST_UP = 2u, ST_POS = 4u;
-template <bool B, class T>
-__device__ __forceinline__ T *pick(T *a, T *b)
+/* A pointer READ from memory (the fields of GenProb) is a generic one to the compiler, and every access through it a flat_
+ * instruction -- which counts as an LDS access too, so that each wait for LDS data waits for all of them.  The arrays of
+ * the iteration are therefore held as pointers into the global address space. */
+#define GKM_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GKM_GLOBAL T *as_global(T *p)
+{
+    return (GKM_GLOBAL T *)p;
+}
+template <bool B, class Ta, class Tb>
+__device__ __forceinline__ auto pick(Ta a, Tb b)
 {
     if constexpr (B) return a; else return b;
 }
@@ -700,10 +709,12 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     unsigned char *const st_s = flag_s + cap;
     const GenProb p = probs[blockIdx.x];
     const int tid = threadIdx.x, l = p.l;
-    int *const gidx = pick<LDS_STATE>((int *)(flag_s + (size_t)14 * cap), p.gidx), *const ys = p.ys, *const aset = p.aset;
-    double *const alpha = p.alpha, *const G = pick<LDS_STATE>((double *)(flag_s + (size_t)2 * cap), p.G), *const Gbar = p.Gbar,
-                  *const QD = p.QD;
-    float *const Qi = pick<LDS_STATE>((float *)(flag_s + (size_t)10 * cap), p.Qi), *const Qj = p.Qj;
+    auto *const gidx = pick<LDS_STATE>((int *)(flag_s + (size_t)14 * cap), as_global(p.gidx));
+    auto *const ys = as_global(p.ys), *const aset = as_global(p.aset);
+    auto *const alpha = as_global(p.alpha), *const Gbar = as_global(p.Gbar), *const QD = as_global(p.QD);
+    auto *const G = pick<LDS_STATE>((double *)(flag_s + (size_t)2 * cap), as_global(p.G));
+    auto *const Qi = pick<LDS_STATE>((float *)(flag_s + (size_t)10 * cap), as_global(p.Qi));
+    auto *const Qj = as_global(p.Qj);
 
     auto is_upper = [&](double a) { return a >= C; };
     auto is_lower = [&](double a) { return a <= 0.0; };
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     __syncthreads();
 
     /* Q_t[k] = (Qfloat)(y_t y_k K_tk) for k in [k0, k1) */
-    auto q_row = [&](int t, float *out, int k0, int k1) {
+    auto q_row = [&](int t, auto *out, int k0, int k1) {
         const double *Kt = K + (int64_t)gidx[t] * ld;
         const int yt = ys[t];
         /* GEN_U positions of a thread at a time, the loads of one kind issued together: the state lives in global
