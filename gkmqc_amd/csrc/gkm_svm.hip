@@ -616,6 +616,9 @@ constexpr int GEN_U = 8; /* positions of a thread whose loads are in flight toge
  * + the shrinking flag), not in L2: a scan then costs LDS reads and ONE dependent trip to the matrix row.  alpha itself
  * (read at i and j only), QD, G_bar and the rest stay in global memory. */
 constexpr int GEN_LDS_L = 8192;
+#ifndef GEN_U_1024
+#define GEN_U_1024 4 /* the 1 024-thread variant has 128 VGPRs: 8 at a time spilt 24 of them (5 folds x 17 600 samples: 0.93 s, 4: 0.79 s) */
+#endif
 #ifndef GEN_U_LDS
 #define GEN_U_LDS 16 /* 512 threads x 16 = every position of such a fold in ONE round of loads */
 #endif
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
                                                        double eps, int max_iter, int shrinking, int cap)
 {
     constexpr int GEN_NW = GEN_T / 64;
-    constexpr int GEN_U = LDS_STATE ? GEN_U_LDS : ::GEN_U;
+    constexpr int GEN_U = LDS_STATE ? GEN_U_LDS : GEN_T == 1024 ? GEN_U_1024 : ::GEN_U;
     __shared__ GenSel sel_s[GEN_NW], selb_s[GEN_NW]; /* first / second selection: one array each (see block_select) */
     __shared__ double max_s[GEN_NW], maxb_s[GEN_NW];
     __shared__ double chunk[GEN_T];
@@ -1341,10 +1344,17 @@ extern "C" int gkmsvm_train_batch_general(int device, const double *K, int64_t l
         if (const char *g = getenv("GKM_SVM_GEN_T")) gt = atoi(g) == 512 ? 512 : 1024;
         bool lds_state = gt == 512 && maxl <= GEN_LDS_L;
         if (const char *g = getenv("GKM_SVM_GEN_LDS")) lds_state = lds_state && atoi(g) != 0;
-        const size_t dyn = lds_state ? (size_t)18 * cap : (size_t)cap;
+        size_t dyn = lds_state ? (size_t)18 * cap : (size_t)cap;
         const void *fn = lds_state ? (const void *)k_smo_general<512, true>
                          : gt == 512 ? (const void *)k_smo_general<512, false> : (const void *)k_smo_general<1024, false>;
         e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        if (e != hipSuccess && lds_state) { /* a device that refuses 147 KB of LDS: the state stays in global memory */
+            (void)hipGetLastError();
+            lds_state = false;
+            dyn = (size_t)cap;
+            fn = (const void *)k_smo_general<512, false>;
+            e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
+        }
         if (e == hipSuccess) {
             if (lds_state)
                 hipLaunchKernelGGL((k_smo_general<512, true>), dim3((unsigned)nprob), dim3(512), dyn, stream, K, ld, diag, dprobs, C,

@@ -40,8 +40,8 @@ extern "C" {
  *                by the caller if the reference's result is wanted
  * Returns 0 on success (work enqueued on `stream`); GKMSVM_RC_SHAPE_REFUSED when the device refuses the launch shape
  * the largest fold needs (its dynamic LDS) -- the one failure after which gkmsvm_train_batch_general is worth trying:
- * it keeps no state in LDS and returns the same bits without shrinking; any other value is an error of the arguments
- * or of the device.
+ * it needs no state in LDS (it keeps some there when the device grants it) and returns the same bits without
+ * shrinking; any other value is an error of the arguments or of the device.
  */
 #define GKMSVM_RC_SHAPE_REFUSED 5
 int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob, const int *idx, const int64_t *off,
@@ -51,9 +51,12 @@ int gkmsvm_train_batch(int device, const double *K, int64_t ld, int n, int nprob
 /*
  * The same with LIBSVM's shrinking heuristic (`shrinking` != 0; scikit-learn `SVC(shrinking=True)`, what the
  * reference's `--shrinking 1` selects, scripts/gkmsvm.py:110-118) and for folds of up to 60 000 samples:
- * Solver::Solve restated with do_shrinking / swap_index / reconstruct_gradient / G_bar, state in global
- * memory, one workgroup per fold.  Bit-identical to scikit-learn with either setting (tests/test_svm_gpu.py);
- * about 2x slower per iteration than gkmsvm_train_batch, which stays the path for gkmQC's default.
+ * Solver::Solve restated with do_shrinking / swap_index / reconstruct_gradient / G_bar, one workgroup per fold,
+ * state in global memory -- for folds of at most 8 192 samples the part of it every iteration scans (gradient, Q_i,
+ * matrix index, one state byte per sample) in LDS instead, 147 KB, if the device grants that.  Bit-identical to
+ * scikit-learn with either setting (tests/test_svm_gpu.py); 1.4x (8 000-sample folds) to 2x slower per iteration than
+ * gkmsvm_train_batch, which stays the path for gkmQC's default.
+ * Environment, for measurements: GKM_SVM_GEN_LDS=0 (state in global memory always), GKM_SVM_GEN_T=512|1024 (threads).
  */
 int gkmsvm_train_batch_general(int device, const double *K, int64_t ld, int n, int nprob, const int *idx,
                                const int64_t *off, const int *n0, double C, double eps, int shrinking, double *alpha,

@@ -118,6 +118,35 @@ def test_general_solver_without_shrinking(built, monkeypatch):
     _compare_with_sklearn(K, 12, [np.array([0, 50])], [np.array([1, 2, 60])], 1.0, 1e-3, shrinking=True)
 
 
+@pytest.mark.parametrize("shrinking", [False, True])
+def test_general_solver_variants_agree(built, monkeypatch, shrinking):
+    """The general solver exists three times: scanned state in LDS (folds of at most 8 192 samples, what the tests above
+    ran), the same 512 threads with the state in global memory (GKM_SVM_GEN_LDS=0), and 1 024 threads (larger folds;
+    GKM_SVM_GEN_T=1024).  Same alpha, gradient, rho and iteration count from all three, bit for bit, on a problem with
+    bounded and free alphas, ties and -- with shrinking -- several rounds of it."""
+    from gkmqc_amd import svmcv
+    monkeypatch.setattr(svmcv, "FAST_FOLD_SAMPLES", 0)
+    K = _rbf_matrix(3000, 3, seed=21, dup=60)
+    import torch
+    Kd = torch.from_numpy(K).cuda()
+    y = np.concatenate((np.repeat(1, 1500), np.repeat(0, 1500)))
+    trains, _ = _folds(3000, 1500, 2, seed=4)
+    got = []
+    for env in ({}, {"GKM_SVM_GEN_LDS": "0"}, {"GKM_SVM_GEN_T": "1024"}):
+        for k in ("GKM_SVM_GEN_LDS", "GKM_SVM_GEN_T"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sol, _ = svmcv.train_folds(Kd, trains, y, 10.0, 1e-5, shrinking)
+        got.append(sol)
+    a = got[0]
+    assert min(a.iters) > 1000
+    for b in got[1:]:
+        assert list(a.iters) == list(b.iters)
+        for f in range(len(trains)):
+            assert np.array_equal(a.alpha[f], b.alpha[f]) and np.array_equal(a.grad[f], b.grad[f]) and a.rho[f] == b.rho[f]
+
+
 def test_large_folds_both_solvers_agree(built, monkeypatch):
     """16 000-sample folds (config 3's size): k_smo's 16-samples-per-thread shape (alpha in LDS, indices and
     diagonal re-read) against the general solver, which keeps its state in global memory -- same alpha, gradient,
