@@ -109,6 +109,16 @@ extern "C" void gkmsvm_release_cache(void)
 }
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+/* A pointer READ from memory (the fields of SvmProb, GenProb, DecProb) is a generic one to the compiler, and every access through it a flat_
+ * instruction -- which counts as an LDS access too, so that each wait for LDS data waits for all of them.  The arrays of
+ * the iteration are therefore held as pointers into the global address space. */
+#define GKM_GLOBAL __attribute__((address_space(1)))
+template <class T>
+__device__ __forceinline__ GKM_GLOBAL T *as_global(T *p)
+{
+    return (GKM_GLOBAL T *)p;
+}
+
 struct SvmProb {
     const int *idx;
     int l, n0;
@@ -254,6 +264,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     __shared__ double g2s[NW];
     __shared__ double chunk[T];
     const SvmProb p = probs[blockIdx.x];
+    const auto *const idx_g = as_global(p.idx);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l = p.l, n0 = p.n0;
 
     /* TAB: the samples' matrix indices and kernel diagonal live in (dynamic) LDS instead of
@@ -275,7 +286,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
-        const int g = k < l ? p.idx[k] : 0;
+        const int g = k < l ? idx_g[k] : 0;
         const double dg = k < l ? diag[g] : 0.0;
         if (TAB) {
             gidx_s[k] = g;
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
     /* (TABM = 2: the index list itself, 64 KB in L2, read again wherever an index is needed -- kept in registers the
      * 16 indices turn into 16 64-bit row offsets that live through the whole iteration) */
     int tv = tid; /* = tid, re-made opaque every iteration so that hipcc does not hoist 16 64-bit addresses out of the loop (they spilt) */
-    auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : QDG ? p.idx[min(tv + r * T, l - 1)] : gidx[TAB || QDG ? 0 : r]; };
+    auto GI = [&](int r) { return TAB ? gidx_s[tid + r * T] : QDG ? idx_g[min(tv + r * T, l - 1)] : gidx[TAB || QDG ? 0 : r]; };
     auto QD = [&](int r) { return QDG ? diag[GI(r)] : TAB ? qd_s[tid + r * T] : qd[TAB || QDG ? 0 : r]; };
 
 #ifdef SVM_PROF
@@ -528,7 +539,7 @@ __global__ __launch_bounds__(T) void k_smo(const double *__restrict__ K, int64_t
 #pragma unroll
     for (int r = 0; r < SVM_R; r++) {
         const int k = tid + r * T;
-        if (k < l) { p.alpha[k] = AL(r); p.grad[k] = k < n0 ? G[r] : -G[r]; }
+        if (k < l) { as_global(p.alpha)[k] = AL(r); as_global(p.grad)[k] = k < n0 ? G[r] : -G[r]; }
     }
 
     /* rho (LIBSVM calculate_rho).  The mean over the free vectors is summed in index order by one
@@ -623,15 +634,6 @@ constexpr int GEN_LDS_L = 8192;
 #define GEN_U_LDS 16 /* 512 threads x 16 = every position of such a fold in ONE round of loads */
 #endif
 constexpr unsigned ST_LO = 1u, ST_UP = 2u, ST_POS = 4u;
-/* A pointer READ from memory (the fields of GenProb) is a generic one to the compiler, and every access through it a flat_
- * instruction -- which counts as an LDS access too, so that each wait for LDS data waits for all of them.  The arrays of
- * the iteration are therefore held as pointers into the global address space. */
-#define GKM_GLOBAL __attribute__((address_space(1)))
-template <class T>
-__device__ __forceinline__ GKM_GLOBAL T *as_global(T *p)
-{
-    return (GKM_GLOBAL T *)p;
-}
 template <bool B, class Ta, class Tb>
 __device__ __forceinline__ auto pick(Ta a, Tb b)
 {
@@ -1178,15 +1180,17 @@ __global__ void k_decision(const double *__restrict__ K, int64_t ld, const DecPr
     const DecProb p = probs[blockIdx.y];
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= p.ntest) return;
-    const int col = p.test[t];
+    const int col = as_global(p.test)[t];
+    const auto *const alpha_g = as_global(p.alpha);
+    const auto *const idx_g = as_global(p.idx);
     double sum = 0;
     for (int k0 = 0; k0 < p.l; k0 += DEC_U) {
         double a[DEC_U], kv[DEC_U];
 #pragma unroll
         for (int u = 0; u < DEC_U; u++) {
             const int k = min(k0 + u, p.l - 1);
-            a[u] = k0 + u < p.l ? p.alpha[k] : 0.0; /* wave-uniform */
-            kv[u] = K[(int64_t)p.idx[k] * ld + col];
+            a[u] = k0 + u < p.l ? alpha_g[k] : 0.0; /* wave-uniform */
+            kv[u] = K[(int64_t)idx_g[k] * ld + col];
         }
 #pragma unroll
         for (int u = 0; u < DEC_U; u++)
