@@ -817,9 +817,22 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
     };
 
     /* Solver::select_working_set; 0 = pair found.  Leaves Q_i[0..active) in Qi. */
+    int sel_yi = 0;                  /* y_i, QD_i, alpha_i of the pair select() found */
+    double sel_QDi = 0, sel_ai = 0;
     auto select = [&](int &out_i, int &out_j) -> int {
         double gm = -INFINITY;
         int gi = -1;
+        /* LDS_STATE (one round of loads per scan): the diagonal entries the SECOND scan needs are asked for here, a scan
+         * and a block selection ahead -- beside the gather of row i they queued behind it in the CU's in-order L1
+         * (26.2 -> 24.2 k cycles per iteration, although the 32 registers spill 11) */
+        double qd_ahead[LDS_STATE ? GEN_U : 1];
+        if constexpr (LDS_STATE) {
+#pragma unroll
+            for (int u = 0; u < GEN_U; u++) {
+                const int k = tid + u * GEN_T;
+                qd_ahead[u] = QD[k < active ? k : 0];
+            }
+        }
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
             double gv[GEN_U];
             unsigned sv[GEN_U];
@@ -847,8 +860,11 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
          * a read and their round trip to L2 per iteration): the thread that computes Q_i[k] uses it at once and stores it
          * for the gradient update and for Q_ij.  Same values, same order of the scan. */
         const double *const Ki = K + (int64_t)gidx[i] * ld;
-        const int yi_ = ys[i];
+        int yi_;
+        if constexpr (LDS_STATE) yi_ = (st_s[i] & ST_POS) ? 1 : -1;
+        else yi_ = ys[i];
         const double QDi = QD[i];
+        sel_yi = yi_; sel_QDi = QDi; sel_ai = alpha[i]; /* (alpha_i is asked for here: it is back long before the update) */
         double gm2 = -INFINITY, omin = INFINITY;
         int gj = -1;
         for (int kb = tid; kb < active; kb += GEN_T * GEN_U) {
@@ -866,7 +882,9 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
 #pragma unroll
           for (int u = 0; u < GEN_U; u++) {
               const int k = kb + u * GEN_T, kc = k < active ? k : kb;
-              gv[u] = G[kc]; sv[u] = st_load(kc); qdv[u] = QD[kc];
+              gv[u] = G[kc]; sv[u] = st_load(kc);
+              if constexpr (LDS_STATE) qdv[u] = qd_ahead[u];
+              else qdv[u] = QD[kc];
           }
           /* Branch-free, one IEEE division per position (k_smo's form of the same arithmetic; a wave holds both labels,
            * and LIBSVM's two branches -- a double division each -- ran one after the other):
@@ -990,8 +1008,11 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
         /* the two-variable update: every thread computes the same scalars.  (Row j is gathered inside the gradient
          * update below, not stored and read back: round 4.)  Qi[j], written by another thread in select(), is visible:
          * the barrier of the second selection came after every thread's writes. */
-        const int yi = ys[i], yj = ys[j];
-        const double old_ai = alpha[i], old_aj = alpha[j], QD_i = QD[i], QD_j = QD[j];
+        const int yi = sel_yi;
+        int yj;
+        if constexpr (LDS_STATE) yj = (st_s[j] & ST_POS) ? 1 : -1;
+        else yj = ys[j];
+        const double old_ai = sel_ai, old_aj = alpha[j], QD_i = sel_QDi, QD_j = QD[j];
         const double *const Kj = K + (int64_t)gidx[j] * ld;
         /* LDS_STATE: one round of loads covers the fold, so the trip to row j starts HERE, under the scalar update (after
          * the loads of the scalars: loads return in order) */
