@@ -21,7 +21,7 @@ from . import device
 
 SHAPE_REFUSED = 5        # GKMSVM_RC_SHAPE_REFUSED (include/gkm_svm.h)
 FAST_FOLD_SAMPLES = 16384  # k_smo: one workgroup per fold, 1024 threads x 16 samples in registers (gkm_svm.hip)
-MAX_FOLD_SAMPLES = 60000   # k_smo_general: state in global memory, also the solver with LIBSVM's shrinking
+MAX_FOLD_SAMPLES = 60000   # k_smo_general: state in global memory (scanned part in LDS up to 8 192 samples), also the solver with LIBSVM's shrinking
 
 
 class SvmError(RuntimeError):
