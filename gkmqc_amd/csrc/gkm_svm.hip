@@ -1114,7 +1114,9 @@ __global__ __launch_bounds__(GEN_T) void k_smo_general(const double *__restrict_
             const bool ui = is_upper(old_ai), uj = is_upper(old_aj);
             if (ui != is_upper(ai)) {
                 __syncthreads();
-                q_row(i, Qi, 0, l);
+                /* Q_i of the active positions is in Qi since the second scan: only the shrunk ones are gathered (from
+                 * a multiple of GEN_T on, so that position k stays with thread k mod GEN_T and no barrier is needed) */
+                q_row(i, Qi, active / GEN_T * GEN_T, l);
                 for (int k = tid; k < l; k += GEN_T) Gbar[k] = ui ? Gbar[k] - C * (double)Qi[k] : Gbar[k] + C * (double)Qi[k];
             }
             if (uj != is_upper(aj)) {
