@@ -1133,15 +1133,19 @@ static bs_kernel_t pick_bitslice(int L, int d)
 #define GKM_BS(LL, DD) \
     if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
     /* every (L, d) with 3 <= L <= 12, d <= min(4, L - 1) (what bin/gkmqc.py:185 can ask for), plus the d > 4 pairs
-     * where this kernel still beats k_gram_direct: a hit costs a whole lane of a trip (~64 lane-instructions), a
-     * comparison 0.45, the general kernel ~5.5 per comparison whatever the hit rate -- break-even at ~8 % of
-     * windows within d mismatches.  iid rates: (12,5) 1.4 %, (11,5) 3.4 %, (12,6) 5.4 %; (10,5) 7.8 %,
-     * (11,6) 11.5 %, (12,7) 15.8 % and everything beyond run faster on the general kernel, which `auto` takes. */
+     * where this kernel still beats k_gram_direct.  Rounds 1-3 put the break-even at ~8 % of the windows within d
+     * mismatches by counting instructions (a hit costs a whole lane of a trip, the general kernel ~5.5 instructions
+     * per comparison) and stopped at (11,5), (12,5), (12,6); round 4 MEASURED it (tools/high_d_ab.py,
+     * profiles/r4_high_d_bitslice_vs_direct.txt: 2 000 x 300 bp iid, every pair with 5 <= d < L <= 12): the general
+     * kernel takes 185-230 ms whatever (L, d), this one 12 ms at (12,5) ... 186 ms at (11,7) (29 % of the windows are
+     * hits) and 227 ms at (12,8) (35 %: a tie).  In: (9,5) 111 ms, (10,5) 52, (10,6) 146, (11,6) 74, (11,7) 186,
+     * (12,7) 101.  Out, slower than the general kernel: (8,5) 217 (a tie), (9,6) 262, (10,7) 311, (11,8) 356, (12,8)
+     * 227 and everything beyond, which `auto` sends to k_gram_direct. */
 #define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
     GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
     GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
     GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
-    GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
+    GKM_BS(9, 5) GKM_BS(10, 5) GKM_BS(10, 6) GKM_BS(11, 5) GKM_BS(11, 6) GKM_BS(11, 7) GKM_BS(12, 5) GKM_BS(12, 6) GKM_BS(12, 7)
 #undef GKM_BS_L
 #undef GKM_BS
     return nullptr;

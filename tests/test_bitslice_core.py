@@ -12,7 +12,8 @@ from tests import helpers
 
 CASES = [(10, 11, 3), (10, 10, 3), (10, 12, 4), (10, 8, 4), (10, 9, 4), (10, 12, 6), (10, 4, 2), (10, 2, 1),
          (10, 3, 0), (10, 5, 2), (10, 6, 3), (10, 7, 3), (5, 11, 3), (16, 11, 3), (3, 12, 4), (10, 12, 8),
-         (10, 12, 12), (10, 11, 1), (10, 11, 5), (10, 12, 5)]
+         (10, 12, 12), (10, 11, 1), (10, 11, 5), (10, 12, 5), (10, 9, 5), (10, 10, 5), (10, 10, 6), (10, 11, 6), (10, 11, 7),
+         (10, 12, 7)]
 
 
 @pytest.fixture(scope="module")

@@ -240,7 +240,8 @@ def test_int32_wraparound_matches_wrapping_arithmetic(dev):
         assert (res["P"].cpu().numpy()[il] == want[il]).all()
 
 
-ALL_LD = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)] + [(11, 5), (12, 5), (12, 6)]
+ALL_LD = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)] + [
+    (9, 5), (10, 5), (10, 6), (11, 5), (11, 6), (11, 7), (12, 5), (12, 6), (12, 7)]
 
 
 @pytest.mark.parametrize("L,d", ALL_LD)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Bit-sliced kernel against the general one (k_gram_direct) at mismatch budgets beyond the product's table (GPU box):
+(L, d) = (10,5), (11,6), (12,7) -- every window pair within d mismatches is a hit, and the rate grows with d / L
+(gkm_device.hip, pick_bitslice: break-even estimated at ~8 % of the windows).  Needs a build whose table holds these pairs:
+
+    tools/build_variant.sh bsx "" HEAD       # then add GKM_BS(10, 5) GKM_BS(11, 6) GKM_BS(12, 7) to pick_bitslice in
+                                             # build_variants/src_bsx/gkmqc_amd/csrc/gkm_device.hip and run its make again
+    GKM_LIB_PATH=build_variants/lib_bsx.so python3 tools/high_d_ab.py [--n 2000] [--length 300]
+
+Prints kernel ms of both kernels per (L, k, d), iid ACGT, kernel type 4, whole lower triangle; the matrices must agree bit for bit.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=2000)
+    ap.add_argument("--length", type=int, default=300)
+    ap.add_argument("--all", action="store_true", help="every (L, d) with 6 <= L <= 12, 5 <= d < L (k = L - d)")
+    a = ap.parse_args()
+    import torch
+    from gkmqc_amd import device, synth
+    seqs = [np.frombuffer(s, np.uint8) for s in synth.make_sequences(1, a.n, a.length)]
+    table = np.zeros(256, np.uint8)
+    for i, ch in enumerate(b"ACGT"):
+        table[ch] = i
+    seqs = [table[s] for s in seqs]
+    print("%d x %d bp, iid ACGT, type 4; kernel ms (second launch)" % (a.n, a.length))
+    pairs = [(L, d) for L in range(6, 13) for d in range(5, L)] if a.all else [(11, 5), (12, 5), (12, 6), (10, 5), (11, 6), (12, 7)]
+    for L, k, d in [(L, L - d, d) for L, d in pairs]:
+        res = {}
+        for name, which in (("bitslice", device.KERNEL_BITSLICE), ("direct", device.KERNEL_DIRECT)):
+            try:
+                for _ in range(2):
+                    r = device.gram_matrix(seqs, 4, L, k, d, kernel=which)
+                res[name] = (r["ms"], r["kernel"], r["K"].cpu().numpy())
+            except device.GkmError as e:
+                res[name] = (None, str(e)[:60], None)
+        b, g = res["bitslice"], res["direct"]
+        same = b[2] is not None and g[2] is not None and np.array_equal(np.tril(b[2]), np.tril(g[2]))
+        print("L=%2d k=%d d=%d   bit-sliced %s   general %s   %s" % (
+            L, k, d, "%8.1f ms (%s)" % (b[0], b[1]) if b[0] else "not built (%s)" % b[1],
+            "%8.1f ms" % g[0] if g[0] else "failed", "bit-identical" if same else "NOT COMPARED" if b[2] is None else "DIFFERENT"), flush=True)
+
+
+if __name__ == "__main__":
+    main()
