@@ -88,7 +88,7 @@ extern "C" int bsprobe_profile(int W, int L, int d, const uint8_t *A, int lenA, 
     CASE(10, 11, 3) CASE(10, 10, 3) CASE(10, 12, 4) CASE(10, 8, 4) CASE(10, 9, 4) CASE(10, 12, 6) CASE(10, 11, 5) CASE(10, 12, 5)
     CASE(10, 4, 2) CASE(10, 2, 1) CASE(10, 3, 0) CASE(10, 5, 2) CASE(10, 6, 3) CASE(10, 7, 3)
     CASE(5, 11, 3) CASE(16, 11, 3) CASE(3, 12, 4) CASE(10, 12, 8) CASE(10, 12, 12) CASE(10, 11, 1)
-    CASE(10, 9, 5) CASE(10, 10, 5) CASE(10, 10, 6) CASE(10, 11, 6) CASE(10, 11, 7) CASE(10, 12, 7) /* the d > 4 pairs round 4 added to the device table */
+    CASE(10, 9, 5) CASE(10, 10, 5) CASE(10, 10, 6) CASE(10, 11, 6) CASE(10, 11, 7) CASE(10, 12, 7) /* more d > 4 pairs (the device table holds (10,5), (11,5), (12,5), (12,6) of them) */
     if (!ok) return 1;
     for (int m = 0; m <= d; m++) P[m] = (int32_t)acc[m];
     return 0;

@@ -963,15 +963,32 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
                 u[r] = ok ? A.lmf[offa + p0 + r] : 0u;
                 wu[r] = u[r] >> 24; /* padding rows have weight 0 and add nothing */
             }
-            for (int qi = 0; qi < nj; qi++) {
-                const uint32_t xf = A.lmf[offj + qi], xr = A.lmr[offj + qi];
-                const uint32_t wf = xf >> 24, wr = xr >> 24;
+            /* The column's l-mers come as SCALARS, eight of each strand per request (s_load_dwordx8 through the constant
+             * address space).  As written in round 1 -- one vector load of a wave-uniform address per column l-mer, waited
+             * for before its sixteen comparisons -- the kernel spent its time on that round trip: 226 ms whatever (L, d)
+             * for 2 000 x 300 bp, of which the LDS read-add-write per hit was 68 (now one ds_add_u32, no return).  The
+             * entries past the column's last l-mer (the next sequence's, or the 8 words of padding behind the table)
+             * are compared like the others and carry the weight 0. */
+            constexpr int QB = 8;
+            const sgpr_words lf = (sgpr_words)(A.lmf + offj), lr = (sgpr_words)(A.lmr + offj);
+            for (int q0 = 0; q0 < nj; q0 += QB) {
+                uint32_t xf[QB], xr[QB];
 #pragma unroll
-                for (int r = 0; r < R; r++) {
-                    int m = gkmbs::lmer_mismatch(u[r], xf);
-                    if (m <= d) acc[m][lane] += wu[r] * wf;
-                    m = gkmbs::lmer_mismatch(u[r], xr);
-                    if (m <= d) acc[m][lane] += wu[r] * wr;
+                for (int t = 0; t < QB; t++) {
+                    xf[t] = lf[q0 + t];
+                    xr[t] = lr[q0 + t];
+                }
+#pragma unroll
+                for (int t = 0; t < QB; t++) {
+                    const bool live = q0 + t < nj;
+                    const uint32_t wf = live ? xf[t] >> 24 : 0u, wr = live ? xr[t] >> 24 : 0u;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int m = gkmbs::lmer_mismatch(u[r], xf[t]);
+                        if (m <= d) atomicAdd(&acc[m][lane], wu[r] * wf);
+                        m = gkmbs::lmer_mismatch(u[r], xr[t]);
+                        if (m <= d) atomicAdd(&acc[m][lane], wu[r] * wr);
+                    }
                 }
             }
         }
@@ -1017,6 +1034,7 @@ __global__ void k_normalize(double *__restrict__ G, int64_t ld, int r0, const do
 static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream);
 static int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream);
 static int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream);
+static bool bitslice_serves(const gkmhip_ctx *ctx); /* which kernel this context's launches take (gram_launch) */
 
 extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
                                     const uint8_t *wdist, int wdist_len, void *stream_)
@@ -1069,8 +1087,8 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
      * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
      * second launch on the other stream before it was complete (found when the host stopped waiting for its
      * uploads: the config-4 stand-in through two contexts differed in a few hundred rows). */
-    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream))) return 4;
-    if (ctx->kernel_pref == GKMHIP_KERNEL_DIRECT && ensure_lmers(ctx, stream)) return 4;
+    if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream))) return 4;
+    if (!bitslice_serves(ctx) && ensure_lmers(ctx, stream)) return 4;
     /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
      * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
     HIPCHK(hipStreamSynchronize(stream));
@@ -1084,7 +1102,7 @@ static int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
     /* one buffer: the reverse-strand table sits lm_stride entries after the forward one, so the hit
      * path selects the strand with an index offset instead of a pointer select */
     if (total_lm >= (size_t)1 << 29) return set_err_msg("l-mer tables exceed 2^29 entries per strand", 4);
-    if (ctx->lmf.ensure(2 * total_lm)) return 4;
+    if (ctx->lmf.ensure(2 * total_lm + 8)) return 4; /* (+ 8: k_gram_direct reads the column's l-mers eight at a time) */
     ctx->lm_stride = (uint32_t)total_lm;
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
                        ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
@@ -1133,22 +1151,44 @@ static bs_kernel_t pick_bitslice(int L, int d)
 #define GKM_BS(LL, DD) \
     if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
     /* every (L, d) with 3 <= L <= 12, d <= min(4, L - 1) (what bin/gkmqc.py:185 can ask for), plus the d > 4 pairs
-     * where this kernel still beats k_gram_direct.  Rounds 1-3 put the break-even at ~8 % of the windows within d
-     * mismatches by counting instructions (a hit costs a whole lane of a trip, the general kernel ~5.5 instructions
-     * per comparison) and stopped at (11,5), (12,5), (12,6); round 4 MEASURED it (tools/high_d_ab.py,
-     * profiles/r4_high_d_bitslice_vs_direct.txt: 2 000 x 300 bp iid, every pair with 5 <= d < L <= 12): the general
-     * kernel takes 185-230 ms whatever (L, d), this one 12 ms at (12,5) ... 186 ms at (11,7) (29 % of the windows are
-     * hits) and 227 ms at (12,8) (35 %: a tie).  In: (9,5) 111 ms, (10,5) 52, (10,6) 146, (11,6) 74, (11,7) 186,
-     * (12,7) 101.  Out, slower than the general kernel: (8,5) 217 (a tie), (9,6) 262, (10,7) 311, (11,8) 356, (12,8)
-     * 227 and everything beyond, which `auto` sends to k_gram_direct. */
+     * where this kernel beats k_gram_direct -- see auto_takes_bitslice() below for where that is. */
 #define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
     GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
     GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
     GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
-    GKM_BS(9, 5) GKM_BS(10, 5) GKM_BS(10, 6) GKM_BS(11, 5) GKM_BS(11, 6) GKM_BS(11, 7) GKM_BS(12, 5) GKM_BS(12, 6) GKM_BS(12, 7)
+    GKM_BS(10, 5) GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
 #undef GKM_BS_L
 #undef GKM_BS
     return nullptr;
+}
+
+/* Which kernel `auto` takes.  The general kernel's time does not depend on (L, d) or on the data; the bit-sliced
+ * kernel's grows with the share of window pairs within d mismatches, every one of which takes a lane of a trip.
+ * Measured in round 4 (tools/high_d_ab.py, profiles/r4_high_d_bitslice_vs_direct.txt; 8 000 x 300 bp iid, whole
+ * triangle): general kernel 810 ms throughout; bit-sliced (12,5) 160 ms at 1.4 % hits, (11,5) 320 at 3.4 %, (12,6) 470
+ * at 5.4 %, (10,5) 690 at 7.8 %, (11,6) 1 000 at 11.5 %, (12,7) 1 360 at 15.8 %, (9,5) 1 500 at 16.6 % -- break-even at
+ * ~9.5 % of the windows, which is where rounds 1-3 had put it by counting instructions (8 %).  (A first measurement on
+ * 2 000 sequences said 30 %: at that size the general kernel's grid did not fill the GPU -- its column chunks now
+ * shrink with the problem.)  The rule is the iid share of (L, d); it also sends the dense pairs of short words --
+ * (8,4) 11 %, (7,4) 24 %, (6,3) 17 %, (5,3) 37 %, ... -- to the general kernel. */
+static double iid_hit_share(int L, int d)
+{
+    double sum = 0.0, term = 1.0; /* C(L, m) 3^m */
+    for (int m = 0; m <= d && m <= L; m++) {
+        sum += term;
+        term = term * 3.0 * (double)(L - m) / (double)(m + 1);
+    }
+    return sum / pow(4.0, (double)L);
+}
+#ifndef GKM_BITSLICE_MAX_HIT_SHARE
+#define GKM_BITSLICE_MAX_HIT_SHARE 0.095
+#endif
+static bool auto_takes_bitslice(int L, int d) { return iid_hit_share(L, d) <= GKM_BITSLICE_MAX_HIT_SHARE; }
+
+static bool bitslice_serves(const gkmhip_ctx *ctx)
+{
+    if (ctx->kernel_pref == GKMHIP_KERNEL_DIRECT || !pick_bitslice<10, 2>(ctx->L, ctx->d)) return false;
+    return ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE || auto_takes_bitslice(ctx->L, ctx->d);
 }
 
 
@@ -1177,6 +1217,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
     if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = pick_bitslice<10, 2>(L, d);
     if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs10)
         return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
+    if (!bitslice_serves(ctx)) bs10 = nullptr; /* auto: the general kernel where it is the faster one */
 
     if (bs10) {
         /* pack the rows into lanes at bit-row granularity (gkm_pack.h) */
@@ -1405,13 +1446,19 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
         A.out = out;
-        A.cj = 16; A.L = L; A.d = d; A.mode = mode; A.n = n;
+        A.L = L; A.d = d; A.mode = mode; A.n = n;
         const unsigned ntiles = (unsigned)((nrows + 63) / 64);
         int span = 0; /* widest column range of any 64-row tile */
+        double items = 0; /* (tile, column) pairs of the launch */
         for (unsigned t = 0; t < ntiles; t++) {
             const int amin = rows[t * 64], amax = rows[std::min<int>((int)t * 64 + 63, nrows - 1)];
-            span = std::max(span, mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1);
+            const int cols = mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1;
+            span = std::max(span, cols);
+            items += cols;
         }
+        /* columns per workgroup: 16 where that still gives the GPU ~16 waves per SIMD, fewer for small problems (2 000
+         * sequences: 2 000 workgroups of 16 columns left three quarters of the SIMDs idle, 156 ms; now 2 columns) */
+        A.cj = (int)std::min(16.0, std::max(1.0, floor(items / 16384.0)));
         const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
         HIPCHK(hipEventRecord(ctx->ev0, stream));
         hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);

@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--n", type=int, default=2000)
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--all", action="store_true", help="every (L, d) with 6 <= L <= 12, 5 <= d < L (k = L - d)")
+    ap.add_argument("--pairs", default="", help='e.g. "10,6 11,7": these (L, d) only')
     a = ap.parse_args()
     import torch
     from gkmqc_amd import device, synth
@@ -33,6 +34,8 @@ def main():
     seqs = [table[s] for s in seqs]
     print("%d x %d bp, iid ACGT, type 4; kernel ms (second launch)" % (a.n, a.length))
     pairs = [(L, d) for L in range(6, 13) for d in range(5, L)] if a.all else [(11, 5), (12, 5), (12, 6), (10, 5), (11, 6), (12, 7)]
+    if a.pairs:
+        pairs = [tuple(int(x) for x in q.split(",")) for q in a.pairs.split()]
     for L, k, d in [(L, L - d, d) for L, d in pairs]:
         res = {}
         for name, which in (("bitslice", device.KERNEL_BITSLICE), ("direct", device.KERNEL_DIRECT)):
