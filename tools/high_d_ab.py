@@ -1,13 +1,18 @@
 #!/usr/bin/env python3
-"""Bit-sliced kernel against the general one (k_gram_direct) at mismatch budgets beyond the product's table (GPU box):
-(L, d) = (10,5), (11,6), (12,7) -- every window pair within d mismatches is a hit, and the rate grows with d / L
-(gkm_device.hip, pick_bitslice: break-even estimated at ~8 % of the windows).  Needs a build whose table holds these pairs:
+"""Bit-sliced kernel against the general one (k_gram_direct), kernel ms and bit-identity of the matrices, per (L, d) (GPU box):
+how round 4 found the break-even that `auto` now goes by (gkm_device.hip auto_takes_bitslice; profiles/r4_high_d_bitslice_vs_direct.txt).
 
-    tools/build_variant.sh bsx "" HEAD       # then add GKM_BS(10, 5) GKM_BS(11, 6) GKM_BS(12, 7) to pick_bitslice in
-                                             # build_variants/src_bsx/gkmqc_amd/csrc/gkm_device.hip and run its make again
-    GKM_LIB_PATH=build_variants/lib_bsx.so python3 tools/high_d_ab.py [--n 2000] [--length 300]
+    python3 tools/high_d_ab.py [--n 2000] [--length 300] [--pairs "10,5 8,4 7,3"]     # pairs of the product's table
+    python3 tools/high_d_ab.py --all                                                   # every pair with 5 <= d < L <= 12
 
-Prints kernel ms of both kernels per (L, k, d), iid ACGT, kernel type 4, whole lower triangle; the matrices must agree bit for bit.
+Pairs the product does not instantiate need a build whose table holds them:
+
+    tools/build_variant.sh bsx "" HEAD       # then extend pick_bitslice in build_variants/src_bsx/gkmqc_amd/csrc/gkm_device.hip
+                                             # (GKM_BS(L, d) ...) and run that directory's make again
+    GKM_LIB_PATH=build_variants/lib_bsx.so python3 tools/high_d_ab.py --all --n 8000
+
+Measure at a realistic size: on 2 000 sequences the general kernel's grid once did not fill the GPU and the comparison misled.
+iid ACGT, kernel type 4, whole lower triangle, second launch of each kernel.
 """
 import argparse
 import os
