@@ -29,15 +29,18 @@ def main():
     ap.add_argument("--length", type=int, default=300)
     ap.add_argument("--all", action="store_true", help="every (L, d) with 6 <= L <= 12, 5 <= d < L (k = L - d)")
     ap.add_argument("--pairs", default="", help='e.g. "10,6 11,7": these (L, d) only')
+    ap.add_argument("--peaks", action="store_true", help="peak-like sequences (synth.make_peak_sequences: GC drift, repeats, shared elements) instead of iid ACGT")
     a = ap.parse_args()
     import torch
     from gkmqc_amd import device, synth
-    seqs = [np.frombuffer(s, np.uint8) for s in synth.make_sequences(1, a.n, a.length)]
+    raw = (synth.make_peak_sequences(11, a.n // 2, a.length, True) + synth.make_peak_sequences(12, a.n - a.n // 2, a.length, False)
+           if a.peaks else synth.make_sequences(1, a.n, a.length))
+    seqs = [np.frombuffer(s, np.uint8) for s in raw]
     table = np.zeros(256, np.uint8)
     for i, ch in enumerate(b"ACGT"):
         table[ch] = i
     seqs = [table[s] for s in seqs]
-    print("%d x %d bp, iid ACGT, type 4; kernel ms (second launch)" % (a.n, a.length))
+    print("%d x %d bp, %s, type 4; kernel ms (second launch)" % (a.n, a.length, "peak-like" if a.peaks else "iid ACGT"))
     pairs = [(L, d) for L in range(6, 13) for d in range(5, L)] if a.all else [(11, 5), (12, 5), (12, 6), (10, 5), (11, 6), (12, 7)]
     if a.pairs:
         pairs = [tuple(int(x) for x in q.split(",")) for q in a.pairs.split()]
