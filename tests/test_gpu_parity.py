@@ -286,6 +286,20 @@ def test_auto_takes_the_faster_kernel(dev):
             assert (auto["K"].cpu().numpy() == other["K"].cpu().numpy()).all()
 
 
+def test_general_kernel_with_several_columns_per_workgroup(dev):
+    """k_gram_direct takes 1..16 columns per workgroup, sized by the problem (one column for the small problems of this
+    suite): 2 600 short ragged sequences make it three columns per workgroup (with a ragged last chunk per tile), against
+    the bit-sliced kernel -- profiles and values bit for bit.  (16 columns: tools/high_d_ab.py --n 8000, same check.)"""
+    rng = np.random.default_rng(29)
+    seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(24, 72, 2600)]
+    a = dev.gram_matrix(seqs, 4, 8, 6, 2, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    b = dev.gram_matrix(seqs, 4, 8, 6, 2, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    assert a["kernel"] == "k_gram_direct" and b["kernel"].startswith("k_gram_bitslice")
+    il = np.tril_indices(len(seqs))
+    assert (a["P"].cpu().numpy()[il] == b["P"].cpu().numpy()[il]).all()
+    assert (a["K"].cpu().numpy() == b["K"].cpu().numpy()).all()
+
+
 def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
     """Fixed-length data normally takes the one-piece-per-lane variant; force the two several-pieces
     variants (64 and 128 row slots per tile) on it as well."""
