@@ -966,7 +966,8 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
             /* The column's l-mers come as SCALARS, eight of each strand per request (s_load_dwordx8 through the constant
              * address space).  As written in round 1 -- one vector load of a wave-uniform address per column l-mer, waited
              * for before its sixteen comparisons -- the kernel spent its time on that round trip: 226 ms whatever (L, d)
-             * for 2 000 x 300 bp, of which the LDS read-add-write per hit was 68 (now one ds_add_u32, no return).  The
+             * for 2 000 x 300 bp, of which the LDS read-add-write per hit was 68 (now one ds_add_u32, no return) and the
+             * starved grid 100 (gram_launch: columns per workgroup by the size of the problem).  The
              * entries past the column's last l-mer (the next sequence's, or the 8 words of padding behind the table)
              * are compared like the others and carry the weight 0. */
             constexpr int QB = 8;
@@ -984,10 +985,11 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
                     const uint32_t wf = live ? xf[t] >> 24 : 0u, wr = live ? xr[t] >> 24 : 0u;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        int m = gkmbs::lmer_mismatch(u[r], xf[t]);
-                        if (m <= d) atomicAdd(&acc[m][lane], wu[r] * wf);
-                        m = gkmbs::lmer_mismatch(u[r], xr[t]);
-                        if (m <= d) atomicAdd(&acc[m][lane], wu[r] * wr);
+                        /* no test for m <= d: acc has a row for every possible m (GKM_MAXD1 = 13 >= L + 1), the rows
+                         * above d are never read.  At the mismatch budgets this kernel serves a fifth to all of the
+                         * pairs are hits anyway, and the compare + EXEC save / restore cost more than the LDS add. */
+                        atomicAdd(&acc[gkmbs::lmer_mismatch(u[r], xf[t])][lane], wu[r] * wf);
+                        atomicAdd(&acc[gkmbs::lmer_mismatch(u[r], xr[t])][lane], wu[r] * wr);
                     }
                 }
             }
@@ -1156,7 +1158,7 @@ static bs_kernel_t pick_bitslice(int L, int d)
     GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
     GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
     GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
-    GKM_BS(10, 5) GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
+    GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
 #undef GKM_BS_L
 #undef GKM_BS
     return nullptr;
@@ -1165,12 +1167,14 @@ static bs_kernel_t pick_bitslice(int L, int d)
 /* Which kernel `auto` takes.  The general kernel's time does not depend on (L, d) or on the data; the bit-sliced
  * kernel's grows with the share of window pairs within d mismatches, every one of which takes a lane of a trip.
  * Measured in round 4 (tools/high_d_ab.py, profiles/r4_high_d_bitslice_vs_direct.txt; 8 000 x 300 bp iid, whole
- * triangle): general kernel 810 ms throughout; bit-sliced (12,5) 160 ms at 1.4 % hits, (11,5) 320 at 3.4 %, (12,6) 470
- * at 5.4 %, (10,5) 690 at 7.8 %, (11,6) 1 000 at 11.5 %, (12,7) 1 360 at 15.8 %, (9,5) 1 500 at 16.6 % -- break-even at
- * ~9.5 % of the windows, which is where rounds 1-3 had put it by counting instructions (8 %).  (A first measurement on
- * 2 000 sequences said 30 %: at that size the general kernel's grid did not fill the GPU -- its column chunks now
- * shrink with the problem.)  The rule is the iid share of (L, d); it also sends the dense pairs of short words --
- * (8,4) 11 %, (7,4) 24 %, (6,3) 17 %, (5,3) 37 %, ... -- to the general kernel. */
+ * triangle): general kernel 688 ms throughout (7.9e12 comparisons/s; 810 before it dropped the test for m <= d, ~1 160
+ * as rounds 1-3 had it); bit-sliced (12,5) 152 ms at 1.4 % hits, (11,5) 329 at 3.4 %, (9,4) 454 at 4.9 %, (12,6) 485 at
+ * 5.4 %, (7,3) 618 at 7.1 %, (10,5) 717 at 7.8 %, (11,6) 1 000 at 11.5 %, (8,4) 1 021 at 11.4 % -- break-even at ~7.5 % of
+ * the windows, close to where rounds 1-3 had put it by counting instructions (8 %).  (A first measurement on 2 000
+ * sequences said 30 %: at that size the general kernel's grid did not fill the GPU -- its column chunks now shrink
+ * with the problem.)  The rule is the iid share of (L, d); it also sends the dense pairs of short words -- (8,4) 11 %,
+ * (7,4) 24 %, (6,3) 17 %, (5,2) 10 %, ... -- to the general kernel, up to 3.1x faster there.  Peak-like data costs the
+ * bit-sliced kernel ~4 % more at the threshold; (7,3) keeps its lead there. */
 static double iid_hit_share(int L, int d)
 {
     double sum = 0.0, term = 1.0; /* C(L, m) 3^m */
@@ -1181,7 +1185,7 @@ static double iid_hit_share(int L, int d)
     return sum / pow(4.0, (double)L);
 }
 #ifndef GKM_BITSLICE_MAX_HIT_SHARE
-#define GKM_BITSLICE_MAX_HIT_SHARE 0.095
+#define GKM_BITSLICE_MAX_HIT_SHARE 0.075
 #endif
 static bool auto_takes_bitslice(int L, int d) { return iid_hit_share(L, d) <= GKM_BITSLICE_MAX_HIT_SHARE; }
 

@@ -57,7 +57,7 @@ int gkmhip_device_of(const gkmhip_ctx *ctx);
 void gkmhip_set_error_message(const char *msg); /* what gkmhip_last_error() returns next (calling thread) */
 
 /* choose the kernel family (default AUTO: the bit-sliced kernel where it is instantiated for (L, d) AND the faster one --
- * at most ~9.5 % of the window pairs within d mismatches for iid sequences --, the general kernel elsewhere;
+ * at most ~7.5 % of the window pairs within d mismatches for iid sequences --, the general kernel elsewhere;
  * BITSLICE fails where the kernel is not instantiated) */
 /* Per-launch scratch (row tables of one gkmhip_gram_rows* call) exists twice.  A caller that issues
  * consecutive launches on two different streams, so that one launch fills the CUs the previous one is

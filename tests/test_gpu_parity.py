@@ -240,7 +240,7 @@ def test_int32_wraparound_matches_wrapping_arithmetic(dev):
         assert (res["P"].cpu().numpy()[il] == want[il]).all()
 
 
-ALL_LD = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)] + [(10, 5), (11, 5), (12, 5), (12, 6)]
+ALL_LD = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)] + [(11, 5), (12, 5), (12, 6)]
 
 
 @pytest.mark.parametrize("L,d", ALL_LD)
@@ -268,14 +268,14 @@ def test_every_bitslice_instantiation_against_the_general_kernel(dev, L, d):
 
 
 def test_auto_takes_the_faster_kernel(dev):
-    """`auto` sends an (L, d) whose iid share of window pairs within d mismatches exceeds ~9.5 % to the general kernel,
+    """`auto` sends an (L, d) whose iid share of window pairs within d mismatches exceeds ~7.5 % to the general kernel,
     although the bit-sliced one is instantiated for it (every hit takes a lane of a trip there; measured break-even,
     profiles/r4_high_d_bitslice_vs_direct.txt), and takes the bit-sliced kernel below that.  Same numbers either way."""
     rng = np.random.default_rng(17)
     seqs = [rng.integers(0, 4, int(n)).astype(np.uint8) for n in rng.integers(40, 400, 90)]
     il = np.tril_indices(len(seqs))
-    for L, d, want in ((11, 3, "bitslice"), (10, 5, "bitslice"), (7, 3, "bitslice"), (12, 6, "bitslice"),
-                       (8, 4, "direct"), (6, 3, "direct"), (5, 4, "direct"), (11, 6, "direct"), (10, 7, "direct")):
+    for L, d, want in ((11, 3, "bitslice"), (7, 3, "bitslice"), (12, 6, "bitslice"), (9, 4, "bitslice"),
+                       (10, 5, "direct"), (8, 4, "direct"), (6, 3, "direct"), (5, 4, "direct"), (11, 6, "direct"), (10, 7, "direct")):
         auto = dev.gram_matrix(seqs, 4, L, L - d, d, want_profiles=True)
         assert ("bitslice" in auto["kernel"]) == (want == "bitslice"), (L, d, auto["kernel"])
         other = dev.gram_matrix(seqs, 4, L, L - d, d, want_profiles=True,
