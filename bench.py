@@ -45,7 +45,9 @@ sys.path.insert(0, ROOT)
 # sustains on the box (profiles/*valu_peak*): both are reported.
 PEAK_INT32_GOPS = 256 * 4 * 32 * 2.4
 OPS_PER_COMPARISON = 6            # op model of SURVEY.md §8(d): xor, shift, or, and, popcount, compare
-KERNEL_SOURCES = ("gkmqc_amd/csrc/gkm_device.hip", "gkmqc_amd/csrc/gkm_bitslice.h", "gkmqc_amd/csrc/gkm_pack.h")
+# the hot kernel, its per-lane arithmetic, the row packing and the launch geometry (work-item order, tables)
+KERNEL_SOURCES = ("gkmqc_amd/csrc/gkm_gram_bitslice.hip", "gkmqc_amd/csrc/gkm_gram_bitslice.h", "gkmqc_amd/csrc/gkm_bitslice.h",
+                  "gkmqc_amd/csrc/gkm_pack.h", "gkmqc_amd/csrc/gkm_gram.hip")
 
 # name: (n_pos, n_neg, length, length_range, kernel_type, L, k, d, generator, label)
 WORKLOADS = {

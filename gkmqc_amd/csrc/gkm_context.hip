@@ -1,0 +1,391 @@
+/*
+ * gkm_context.hip -- MI355X (gfx950) device layer of the gkm kernel-matrix path: context, upload and the per-sequence
+ * device tables.  Implements the first part of include/gkm_hip.h (see gkm_internal.h for the other translation units).
+ *
+ * Kernels
+ *   k_build_sb        column-strand bit-plane tables, strided layout (gkm_bitslice.h)
+ *   k_pack_strands    both strands of every sequence, 16 bases per word (the hit path's column side)
+ *   k_pack_lmers      per-l-mer tables of the general kernel (k_gram_direct)
+ */
+#include "gkm_gram_bitslice.h" /* (BS_DU pads the SB tables) */
+
+/* ------------------------------------------------------------------ errors */
+static thread_local std::string g_err;
+
+int gkm_set_err(const char *what, hipError_t e, const char *file, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof buf, "%s: %s (%s:%d)", what, hipGetErrorString(e), file, line);
+    g_err = buf;
+    return 100 + (int)e;
+}
+int gkm_set_err_msg(const std::string &m, int code)
+{
+    g_err = m;
+    return code;
+}
+extern "C" const char *gkmhip_last_error(void) { return g_err.c_str(); }
+/* (used by gkm_multi.hip so that one call reports every layer's failures) */
+extern "C" void gkmhip_set_error_message(const char *msg) { g_err = msg ? msg : ""; }
+
+extern "C" int gkmhip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int gkmhip_current_device(void)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return -1;
+    return dev;
+}
+
+extern "C" int gkmhip_set_current_device(int device)
+{
+    HIPCHK(hipSetDevice(device));
+    return 0;
+}
+
+/* Pinned staging for device-to-host copies, kept for the life of the process: the pipeline
+ * calls the boundary once per peak subset (20x per run, bin/gkmqc.py:341-343) and pinning
+ * 2 x 64 MB costs ~30 ms per call otherwise.  gkmhip_release_host_cache() frees it. */
+static std::mutex g_stage_mutex;
+static double *g_stage[STAGE_SLOTS][2];
+static size_t g_stage_bytes[STAGE_SLOTS];
+
+int acquire_staging(size_t want, double **out, int slot)
+{
+    if (slot < 0 || slot >= STAGE_SLOTS) return set_err_msg("too many device threads", 2);
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    if (g_stage_bytes[slot] < want) {
+        for (int i = 0; i < 2; i++) {
+            if (g_stage[slot][i]) (void)hipHostFree(g_stage[slot][i]);
+            g_stage[slot][i] = nullptr;
+        }
+        g_stage_bytes[slot] = 0;
+        for (int i = 0; i < 2; i++) HIPCHK(hipHostMalloc((void **)&g_stage[slot][i], want, hipHostMallocPortable));
+        g_stage_bytes[slot] = want;
+    }
+    out[0] = g_stage[slot][0];
+    out[1] = g_stage[slot][1];
+    return 0;
+}
+
+/* Host side of the per-launch table uploads: a process-wide pool of pinned buffers, so that the upload is a true
+ * asynchronous copy from memory that outlives the call.  A buffer is handed back by a host function enqueued on
+ * the stream right behind the copy (hipLaunchHostFunc: it runs when the copy engine has finished reading), so
+ * no thread ever waits for, or queries, an event of another thread's stream.  A pool, not one buffer per
+ * context: the boundary call enqueues 13 launches up front, and waiting for the previous upload would make the
+ * host follow the device launch by launch (measured: 81 ms of enqueueing instead of 2.5, the copy-out pipeline
+ * starting only when the compute was over). */
+static std::mutex g_pin_mutex;
+static std::vector<PinBuf *> g_pin;
+
+void pin_release(void *ud) { ((PinBuf *)ud)->in_use.store(0, std::memory_order_release); }
+
+PinBuf *pin_acquire(size_t bytes)
+{
+    PinBuf *b = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        for (PinBuf *c : g_pin)
+            if (c->in_use.load(std::memory_order_acquire) == 0 && (!b || (c->cap >= bytes && b->cap < bytes))) b = c;
+        if (!b) {
+            b = new PinBuf();
+            g_pin.push_back(b);
+        }
+        b->in_use.store(1, std::memory_order_relaxed);
+    }
+    if (b->cap < bytes) { /* (this thread owns b now) */
+        if (b->p) (void)hipHostFree(b->p);
+        b->p = nullptr;
+        b->cap = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+        if (hipHostMalloc((void **)&b->p, want, hipHostMallocPortable) != hipSuccess) {
+            b->in_use.store(0);
+            return nullptr;
+        }
+        b->cap = want;
+    }
+    return b;
+}
+
+extern "C" void gkmhip_release_host_cache(void)
+{
+    {
+        std::lock_guard<std::mutex> lock(g_pin_mutex);
+        for (PinBuf *b : g_pin)
+            if (b->in_use.load() == 0 && b->p) {
+                (void)hipHostFree(b->p);
+                b->p = nullptr;
+                b->cap = 0;
+            }
+    }
+    gkm_release_pipe_streams();
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
+    for (int s = 0; s < STAGE_SLOTS; s++) {
+        for (int i = 0; i < 2; i++) {
+            if (g_stage[s][i]) (void)hipHostFree(g_stage[s][i]);
+            g_stage[s][i] = nullptr;
+        }
+        g_stage_bytes[s] = 0;
+    }
+}
+
+extern "C" gkmhip_ctx *gkmhip_create(int device, int L, int d, const double *c, int rbf, double gamma)
+{
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_err = "no HIP device available (hipGetDeviceCount)";
+        return nullptr;
+    }
+    if (device < 0 || device >= ndev) { g_err = "device ordinal out of range"; return nullptr; }
+    if (L < 2 || L > 12 || d < 0 || d > 12 || d > L) { g_err = "unsupported (L, d)"; return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    gkmhip_ctx *ctx = new gkmhip_ctx();
+    ctx->device = device;
+    ctx->L = L;
+    ctx->d = d;
+    ctx->rbf = rbf;
+    ctx->gamma = gamma;
+    for (int m = 0; m <= d; m++) ctx->c[m] = c[m];
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        g_err = "hipEventCreate failed";
+        delete ctx;
+        return nullptr;
+    }
+    const char *env = getenv("GKM_KERNEL");
+    if (env) {
+        if (!strcmp(env, "direct")) ctx->kernel_pref = GKMHIP_KERNEL_DIRECT;
+        else if (!strcmp(env, "bitslice")) ctx->kernel_pref = GKMHIP_KERNEL_BITSLICE;
+    }
+    return ctx;
+}
+
+extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    /* (hipFree waits for the work that may still use the buffers; no separate device-wide wait) */
+    ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release();
+    for (auto &scr : ctx->scratch) scr.release();
+    ctx->sq.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+extern "C" int gkmhip_n_sequences(const gkmhip_ctx *ctx) { return ctx ? ctx->n : 0; }
+extern "C" int gkmhip_device_of(const gkmhip_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+extern "C" int gkmhip_set_scratch_slot(gkmhip_ctx *ctx, int slot)
+{
+    if (!ctx || slot < 0 || slot >= GKM_SCRATCH_SLOTS) return set_err_msg("bad scratch slot", 2);
+    ctx->sel = slot;
+    return 0;
+}
+
+extern "C" int gkmhip_set_kernel(gkmhip_ctx *ctx, int which)
+{
+    if (!ctx || which < 0 || which > 2) return set_err_msg("bad kernel selector", 2);
+    ctx->kernel_pref = which;
+    return 0;
+}
+
+/* ----------------------------------------------------------- prep kernels */
+/* one workgroup per sequence: l-mer table entries (gkm_bitslice.h lmer_entry) of the forward
+ * strand and of the reverse-complement strand (rc l-mer p = l-mer p of rc(seq),
+ * libgkm.c:877-888), each with its positional weight in the top byte: wt[p] = wd[|n/2 - p|],
+ * wt_rc[p] = wt[n-1-p] (libgkm.c:912-925); all weights 1 for the unweighted kernel types */
+__global__ void k_pack_lmers(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
+                             const int64_t *__restrict__ lmoff, int L, const uint8_t *__restrict__ wd,
+                             int weighted, uint32_t *__restrict__ lmf, uint32_t *__restrict__ lmr)
+{
+    const int s = blockIdx.x;
+    const uint8_t *seq = codes + off[s];
+    const int len = (int)(off[s + 1] - off[s]);
+    const int n = len - L + 1;
+    const int64_t o = lmoff[s];
+    for (int p = threadIdx.x; p < n; p += blockDim.x) {
+        const uint32_t wf = weighted ? gkmbs::dist_weight(wd, n / 2, p) : 1u;
+        const uint32_t wr = weighted ? gkmbs::dist_weight(wd, n / 2, n - 1 - p) : 1u;
+        lmf[o + p] = gkmbs::lmer_entry(seq, len, L, 0, p, wf);
+        lmr[o + p] = gkmbs::lmer_entry(seq, len, L, 1, p, wr);
+    }
+}
+
+/* grid (sequence*2+strand); threads over the words of the strand's 2-bit packed copy (gkm_bitslice.h pk_word).
+ * The two strands of a sequence are interleaved word by word, colpk[(seq * pkw + x) * 2 + strand]: the hot kernel
+ * copies the 2 * pkw words of a column to LDS as they are, and a hit reads words x and x + 1 of its strand at byte
+ * offset (x * 8) | (strand * 4) -- the strand costs the address one OR instead of a multiply-add */
+__global__ void k_pack_strands(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int pkw,
+                               uint32_t *__restrict__ colpk)
+{
+    const int e = blockIdx.x, s = e >> 1, strand = e & 1;
+    const uint8_t *seq = codes + off[s];
+    const int T = (int)(off[s + 1] - off[s]);
+    for (int x = threadIdx.x; x < pkw; x += blockDim.x)
+        colpk[((size_t)s * pkw + x) * 2 + strand] = gkmbs::pk_word(seq, T, strand, x);
+}
+
+/* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
+__global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
+                           int L, int xw, uint32_t *__restrict__ sb)
+{
+    const int e = blockIdx.x, plane = blockIdx.y;
+    const int s = e >> 1, strand = e & 1;
+    const uint8_t *seq = codes + off[s];
+    const int T = (int)(off[s + 1] - off[s]);
+    uint32_t *dst = sb + ((size_t)e * 2 + plane) * xw; /* planes: 0 = hi bit, 1 = lo bit of the base code */
+    for (int x = threadIdx.x; x < xw; x += blockDim.x)
+        dst[x] = (x < T + W) ? gkmbs::sb_word(seq, T, strand, x, W, L, plane) : 0u;
+}
+
+/* ---------------------------------------------------------- host: upload */
+extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes, const int64_t *offsets,
+                                    const uint8_t *wdist, int wdist_len, void *stream_)
+{
+    if (!ctx || n <= 0 || !codes || !offsets) return set_err_msg("gkmhip_set_sequences: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    HIPCHK(hipSetDevice(ctx->device));
+    const int L = ctx->L;
+    const int weighted = (wdist != nullptr && wdist_len > 0) ? 1 : 0;
+    /* a context may be reused for another set of sequences (gkmsvm.init_many keeps one per device): every
+     * per-sequence table of the previous set is stale from here on, BEFORE anything below sizes itself by them */
+    ctx->have_lmers = false;
+    ctx->have_sb = false;
+    ctx->have_colpk = false;
+    ctx->n = 0;
+    ctx->weighted = weighted;
+    ctx->h_len.resize((size_t)n);
+    ctx->h_lmoff.resize((size_t)n + 1);
+    ctx->h_cum_n.resize((size_t)n + 1);
+    ctx->h_lmoff[0] = 0;
+    ctx->h_cum_n[0] = 0.0;
+    ctx->maxlen = 0;
+    for (int i = 0; i < n; i++) {
+        const int64_t len = offsets[i + 1] - offsets[i];
+        if (len < L) return set_err_msg("sequence " + std::to_string(i) + " is shorter than L", 3);
+        if (len > 2047) return set_err_msg("sequence longer than 2047", 3);
+        ctx->h_len[(size_t)i] = (int)len;
+        ctx->h_lmoff[(size_t)i + 1] = ctx->h_lmoff[(size_t)i] + (len - L + 1);
+        ctx->h_cum_n[(size_t)i + 1] = ctx->h_cum_n[(size_t)i] + (double)(len - L + 1);
+        ctx->maxlen = std::max(ctx->maxlen, (int)len);
+    }
+    ctx->n = n;
+    if (weighted && (wdist_len <= (ctx->maxlen - L + 1) / 2 || wdist_len > WD_LDS))
+        return set_err_msg("distance weight table must cover 0..max(n)/2 and hold at most 1024 entries", 3);
+    const size_t total = (size_t)offsets[n];
+    if (ctx->codes.ensure(total) || ctx->off.ensure((size_t)n + 1) || ctx->lmoff.ensure((size_t)n + 1) ||
+        ctx->len.ensure((size_t)n) || ctx->wd.ensure(WD_LDS))
+        return 4;
+    HIPCHK(hipMemcpyAsync(ctx->codes.p, codes, total, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->off.p, offsets, ((size_t)n + 1) * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->lmoff.p, ctx->h_lmoff.data(), ((size_t)n + 1) * sizeof(int64_t),
+                          hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(ctx->len.p, ctx->h_len.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+    /* unweighted kernel types: every positional weight is 1 (libgkm.c:926-932) -- a table of ones keeps the
+     * hit path free of a weighted / unweighted branch */
+    HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
+    if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
+    ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
+    /* The per-sequence device tables are built HERE, not at the first launch: callers alternate launches between
+     * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
+     * second launch on the other stream before it was complete (found when the host stopped waiting for its
+     * uploads: the config-4 stand-in through two contexts differed in a few hundred rows). */
+    if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream))) return 4;
+    if (!bitslice_serves(ctx) && ensure_lmers(ctx, stream)) return 4;
+    /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
+     * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
+    HIPCHK(hipStreamSynchronize(stream));
+    return 0;
+}
+
+int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->have_lmers) return 0;
+    const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
+    /* one buffer: the reverse-strand table sits lm_stride entries after the forward one, so the hit
+     * path selects the strand with an index offset instead of a pointer select */
+    if (total_lm >= (size_t)1 << 29) return set_err_msg("l-mer tables exceed 2^29 entries per strand", 4);
+    if (ctx->lmf.ensure(2 * total_lm + 8)) return 4; /* (+ 8: k_gram_direct reads the column's l-mers eight at a time) */
+    ctx->lm_stride = (uint32_t)total_lm;
+    hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
+                       ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    ctx->have_lmers = true;
+    return 0;
+}
+
+int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->have_colpk) return 0;
+    /* one word more than the bases need: the hit path reads words q/16 and q/16 + 1 */
+    const int pkw = (ctx->maxlen + 15) / 16 + 1;
+    if (ctx->colpk.ensure((size_t)ctx->n * 2 * (size_t)pkw)) return 4;
+    hipLaunchKernelGGL(k_pack_strands, dim3((unsigned)ctx->n * 2), dim3(64), 0, stream, ctx->codes.p, ctx->off.p, pkw,
+                       ctx->colpk.p);
+    HIPCHK(hipGetLastError());
+    ctx->pkw = pkw;
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    ctx->have_colpk = true;
+    return 0;
+}
+
+int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
+{
+    if (ctx->have_sb && ctx->sb_W == W) return 0;
+    const int xw = ((ctx->maxlen + W + 2 * BS_DU + 15) / 16) * 16;
+    if (ctx->sb.ensure((size_t)ctx->n * 2 * 2 * (size_t)xw)) return 4;
+    hipLaunchKernelGGL(k_build_sb, dim3((unsigned)ctx->n * 2, 2), dim3(256), 0, stream, ctx->codes.p, ctx->off.p,
+                       W, ctx->L, xw, ctx->sb.p);
+    HIPCHK(hipGetLastError());
+    ctx->sb_xw = xw;
+    ctx->sb_W = W;
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    ctx->have_sb = true;
+    return 0;
+}
+
+/* ------------------------------------------------------- memory helpers */
+extern "C" void *gkmhip_malloc(int device, size_t bytes)
+{
+    void *p = nullptr;
+    if (hipSetDevice(device) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
+    if (e != hipSuccess) { set_err("hipMalloc", e, __FILE__, __LINE__); return nullptr; }
+    return p;
+}
+extern "C" void gkmhip_free(void *p) { if (p) (void)hipFree(p); }
+extern "C" int gkmhip_memcpy_d2h(void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int gkmhip_memcpy_h2d(void *dst, const void *src, size_t bytes)
+{
+    HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int gkmhip_sync(void *stream)
+{
+    if (stream) HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    else HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" double gkmhip_last_kernel_ms(gkmhip_ctx *ctx)
+{
+    if (!ctx || !ctx->ev_valid) return -1.0;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+extern "C" double gkmhip_last_comparisons(gkmhip_ctx *ctx) { return ctx ? ctx->last_comparisons : 0.0; }
+extern "C" const char *gkmhip_last_kernel_name(gkmhip_ctx *ctx) { return ctx ? ctx->last_kernel : "none"; }

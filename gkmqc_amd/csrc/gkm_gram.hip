@@ -1,0 +1,541 @@
+/*
+ * gkm_gram.hip -- one launch of the Gram kernel for a set of rows: which kernel, the row packing (gkm_pack.h), the order
+ * of the work items, the per-launch tables; plus the small kernels either side of the hot one and the general kernel.
+ *
+ * Kernels
+ *   k_build_rowplanes row-segment bit planes + the lanes' packed positions for one set of rows
+ *   k_untile          tile-transposed values -> matrix rows (both sides in 512-byte runs)
+ *   k_gram_direct     general fallback: per-l-mer tables, l-mer by l-mer XOR/popcount (any L <= 12, d <= 12)
+ * (k_gram_bitslice, the hot kernel: gkm_gram_bitslice.hip)
+ */
+#include "gkm_gram_bitslice.h"
+
+/* Packed lanes (gkm_pack.h): grid (tile, plane); 64 threads = the tile's lanes; output layout
+ * [tile][plane][w][lane].  desc holds MAX_PIECES x {row, b0, nb, p0, cnt} per lane (nb = 0: unused).
+ * plane 3: the lane's positions 2-bit packed for the hit path, rowpk[(tile*64 + lane) * rpw + x]
+ * (16 positions per word, position i = bit row i / W, word i % W of the bit planes; rpw = 32 words = 128 bytes
+ * per lane, of which 32 W / 16 + 1 are used). */
+__global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off,
+                                  const int *__restrict__ desc, int W, uint32_t *__restrict__ planes,
+                                  uint32_t *__restrict__ rowpk, int rpw)
+{
+    /* grid (tile, plane, part): planes 0..2 one word w = part per block (part < W), plane 3 four packed words per block
+     * (round 4: one block per (tile, plane) looped over all of them -- 0.7 ms per 10 000 rows, 1 % of a step) */
+    const int tile = blockIdx.x, plane = blockIdx.y, part = blockIdx.z, lane = threadIdx.x;
+    const int *d = desc + (size_t)(tile * 64 + lane) * gkmpack::MAX_PIECES * 5;
+    if (plane == 3) {
+        for (int x = part * 4; x < rpw && x < part * 4 + 4; x++) {
+            uint32_t v = 0u;
+            for (int k = 0; k < gkmpack::MAX_PIECES && x * 16 < 32 * W; k++) { /* (words past the lane's positions: 0) */
+                const int row = d[k * 5 + 0], b0 = d[k * 5 + 1], nb = d[k * 5 + 2], p0 = d[k * 5 + 3];
+                if (nb <= 0) continue;
+                const uint8_t *seq = codes + off[row];
+                const int len = (int)(off[row + 1] - off[row]);
+                for (int q = 0; q < 16; q++) {
+                    const int i = x * 16 + q, b = i / W;
+                    if (b < b0 || b >= b0 + nb) continue;
+                    const int pos = p0 + i - b0 * W;
+                    if (pos < len) v |= (uint32_t)seq[pos] << (2 * q);
+                }
+            }
+            rowpk[(size_t)(tile * 64 + lane) * rpw + x] = v;
+        }
+        return;
+    }
+    for (int w = part; w < W; w += (int)gridDim.z) {
+        uint32_t v = 0u;
+        for (int k = 0; k < gkmpack::MAX_PIECES; k++) {
+            const int row = d[k * 5 + 0], b0 = d[k * 5 + 1], nb = d[k * 5 + 2], p0 = d[k * 5 + 3], cnt = d[k * 5 + 4];
+            if (nb <= 0) continue;
+            const uint8_t *seq = codes + off[row];
+            const int len = (int)(off[row + 1] - off[row]);
+            for (int b = b0; b < b0 + nb; b++) v |= gkmbs::piece_bit(seq, len, b0, nb, p0, cnt, b, w, W, plane) << b;
+        }
+        planes[(((size_t)tile * 3 + plane) * W + w) * 64 + lane] = v;
+    }
+}
+
+/* S (tile-transposed, see BsArgs) -> rows of G.  Block = 64 columns x 64 row slots of one tile, moved
+ * through LDS so that both the reads (64 slots of one column) and the writes (64 columns of one row)
+ * are 512-byte runs.  grid (column blocks, tiles * NSLOT / 64). */
+template <int NSLOT>
+__global__ __launch_bounds__(256) void k_untile(const double *__restrict__ S, const int64_t *__restrict__ tile_soff,
+                                                const int *__restrict__ tile_cbeg, const int *__restrict__ tile_cend,
+                                                const int *__restrict__ tile_nrows, const int *__restrict__ tile_row,
+                                                const int *__restrict__ tile_out, GramOut out)
+{
+    __shared__ double buf[64][65];
+    const int tile = blockIdx.y / (NSLOT / 64), half = blockIdx.y % (NSLOT / 64);
+    const int cbeg = tile_cbeg[tile], cend = tile_cend[tile], nrows = tile_nrows[tile];
+    const int jb = cbeg + (int)blockIdx.x * 64;
+    if (jb >= cend || half * 64 >= nrows) return;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const double *src = S + (tile_soff[tile] + (jb - cbeg)) * NSLOT + half * 64;
+    for (int c = ty; c < 64; c += 4)
+        if (jb + c < cend && half * 64 + tx < nrows) buf[c][tx] = src[(int64_t)c * NSLOT + tx];
+    __syncthreads();
+    for (int rl = ty; rl < 64; rl += 4) {
+        const int rs = half * 64 + rl;
+        if (rs >= nrows) break;
+        const int row = tile_row[tile * gkmpack::MAX_ROWS + rs];
+        const int j = jb + tx;
+        if (j >= cend || (j > row && !out.write_all)) continue;
+        const int64_t r = out.local_rows ? tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
+        *gram_cell(out, r, j) = buf[tx][rl];
+    }
+}
+
+struct DirectArgs {
+    const int *rows;
+    int nrows;
+    const int *len;
+    const int64_t *lmoff;
+    const uint32_t *lmf, *lmr; /* l-mer | weight << 24 */
+    double c[GKM_MAXD1];
+    GramOut out;
+    int cj, L, d, mode, n;
+};
+
+/*
+ * General fallback (any L <= 12, d <= 12): lane = row sequence, R row l-mers held in
+ * registers, the column strand's packed l-mers streamed as wave-uniform scalars;
+ * XOR / fold / popcount per comparison, rare exec-masked accumulate.
+ */
+__global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
+{
+    constexpr int R = 8;
+    __shared__ uint32_t acc[GKM_MAXD1][64];
+    const int lane = threadIdx.x;
+    const int tile = blockIdx.y;
+    const int ridx = tile * 64 + lane;
+    const int a = ridx < A.nrows ? A.rows[ridx] : -1;
+    const int amin = A.rows[tile * 64], amax = A.rows[min(tile * 64 + 63, A.nrows - 1)];
+    const int cbeg = A.mode == COLS_DIAGONAL ? amin : 0, cend = A.mode == COLS_FULL ? A.n : amax + 1;
+    const int j0 = cbeg + blockIdx.x * A.cj;
+    const int j1 = min(j0 + A.cj, cend);
+    if (j0 >= j1) return;
+    const int d = A.d;
+    const int na = a >= 0 ? A.len[a] - A.L + 1 : 0;
+    const int64_t offa = a >= 0 ? A.lmoff[a] : 0;
+    int namax = na;
+    for (int s = 32; s >= 1; s >>= 1) namax = max(namax, __shfl_xor(namax, s));
+
+    for (int j = j0; j < j1; j++) {
+        const int nj = A.len[j] - A.L + 1;
+        const int64_t offj = A.lmoff[j];
+        for (int m = 0; m <= d; m++) acc[m][lane] = 0u;
+        for (int p0 = 0; p0 < namax; p0 += R) {
+            uint32_t u[R], wu[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const bool ok = (p0 + r) < na;
+                u[r] = ok ? A.lmf[offa + p0 + r] : 0u;
+                wu[r] = u[r] >> 24; /* padding rows have weight 0 and add nothing */
+            }
+            /* The column's l-mers come as SCALARS, eight of each strand per request (s_load_dwordx8 through the constant
+             * address space).  As written in round 1 -- one vector load of a wave-uniform address per column l-mer, waited
+             * for before its sixteen comparisons -- the kernel spent its time on that round trip: 226 ms whatever (L, d)
+             * for 2 000 x 300 bp, of which the LDS read-add-write per hit was 68 (now one ds_add_u32, no return) and the
+             * starved grid 100 (gram_launch: columns per workgroup by the size of the problem).  The
+             * entries past the column's last l-mer (the next sequence's, or the 8 words of padding behind the table)
+             * are compared like the others and carry the weight 0. */
+            constexpr int QB = 8;
+            const sgpr_words lf = (sgpr_words)(A.lmf + offj), lr = (sgpr_words)(A.lmr + offj);
+            for (int q0 = 0; q0 < nj; q0 += QB) {
+                uint32_t xf[QB], xr[QB];
+#pragma unroll
+                for (int t = 0; t < QB; t++) {
+                    xf[t] = lf[q0 + t];
+                    xr[t] = lr[q0 + t];
+                }
+#pragma unroll
+                for (int t = 0; t < QB; t++) {
+                    const bool live = q0 + t < nj;
+                    const uint32_t wf = live ? xf[t] >> 24 : 0u, wr = live ? xr[t] >> 24 : 0u;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        /* no test for m <= d: acc has a row for every possible m (GKM_MAXD1 = 13 >= L + 1), the rows
+                         * above d are never read.  At the mismatch budgets this kernel serves a fifth to all of the
+                         * pairs are hits anyway, and the compare + EXEC save / restore cost more than the LDS add. */
+                        atomicAdd(&acc[gkmbs::lmer_mismatch(u[r], xf[t])][lane], wu[r] * wf);
+                        atomicAdd(&acc[gkmbs::lmer_mismatch(u[r], xr[t])][lane], wu[r] * wr);
+                    }
+                }
+            }
+        }
+        if (a >= 0 && (j <= a || A.out.write_all)) {
+            double g = 0.0;
+            for (int m = 0; m <= d; m++) g += A.c[m] * (double)(int32_t)acc[m][lane];
+            const int64_t r = A.out.local_rows ? ridx : a;
+            if (A.out.diag && j == a) A.out.diag[a] = g;
+            if (A.out.G) *gram_cell(A.out, r, j) = g;
+            if (A.out.P)
+                for (int m = 0; m <= d; m++) A.out.P[(r * A.out.ldp + j) * (d + 1) + m] = (int32_t)acc[m][lane];
+        }
+    }
+}
+
+/* Which kernel `auto` takes.  The general kernel's time does not depend on (L, d) or on the data; the bit-sliced
+ * kernel's grows with the share of window pairs within d mismatches, every one of which takes a lane of a trip.
+ * Measured in round 4 (tools/high_d_ab.py, profiles/r4_high_d_bitslice_vs_direct.txt; 8 000 x 300 bp iid, whole
+ * triangle): general kernel 688 ms throughout (7.9e12 comparisons/s; 810 before it dropped the test for m <= d, ~1 160
+ * as rounds 1-3 had it); bit-sliced (12,5) 152 ms at 1.4 % hits, (11,5) 329 at 3.4 %, (9,4) 454 at 4.9 %, (12,6) 485 at
+ * 5.4 %, (7,3) 618 at 7.1 %, (10,5) 717 at 7.8 %, (11,6) 1 000 at 11.5 %, (8,4) 1 021 at 11.4 % -- break-even at ~7.5 % of
+ * the windows, close to where rounds 1-3 had put it by counting instructions (8 %).  (A first measurement on 2 000
+ * sequences said 30 %: at that size the general kernel's grid did not fill the GPU -- its column chunks now shrink
+ * with the problem.)  The rule is the iid share of (L, d); it also sends the dense pairs of short words -- (8,4) 11 %,
+ * (7,4) 24 %, (6,3) 17 %, (5,2) 10 %, ... -- to the general kernel, up to 3.1x faster there.  Peak-like data costs the
+ * bit-sliced kernel ~4 % more at the threshold; (7,3) keeps its lead there. */
+static double iid_hit_share(int L, int d)
+{
+    double sum = 0.0, term = 1.0; /* C(L, m) 3^m */
+    for (int m = 0; m <= d && m <= L; m++) {
+        sum += term;
+        term = term * 3.0 * (double)(L - m) / (double)(m + 1);
+    }
+    return sum / pow(4.0, (double)L);
+}
+#ifndef GKM_BITSLICE_MAX_HIT_SHARE
+#define GKM_BITSLICE_MAX_HIT_SHARE 0.075
+#endif
+static bool auto_takes_bitslice(int L, int d) { return iid_hit_share(L, d) <= GKM_BITSLICE_MAX_HIT_SHARE; }
+
+bool bitslice_serves(const gkmhip_ctx *ctx)
+{
+    if (ctx->kernel_pref == GKMHIP_KERNEL_DIRECT || !gkm_pick_bitslice(2, ctx->L, ctx->d)) return false;
+    return ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE || auto_takes_bitslice(ctx->L, ctx->d);
+}
+
+
+/* One launch of the Gram kernel for a set of rows.  mode says which columns every tile of rows
+ * visits: COLS_TRIANGLE j <= largest row of the tile (the path of gkm_main_pywrapper),
+ * COLS_FULL every sequence, COLS_DIAGONAL only the band of the tile's own rows (self norms). */
+static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, GramOut out, hipStream_t stream)
+{
+    if (!ctx || !rows || nrows <= 0) return set_err_msg("gram: bad arguments", 2);
+    if (ctx->n <= 0) return set_err_msg("gram: no sequences uploaded", 2);
+    HIPCHK(hipSetDevice(ctx->device));
+    (void)hipGetLastError(); /* the launch checks below must see this call's errors only */
+    const int L = ctx->L, d = ctx->d, n = ctx->n;
+    double comparisons = 0;
+    for (int i = 0; i < nrows; i++) {
+        if (rows[i] < 0 || rows[i] >= n || (i > 0 && rows[i] <= rows[i - 1]))
+            return set_err_msg("rows must be strictly ascending sequence indices", 2);
+        const double na = (double)(ctx->h_len[(size_t)rows[i]] - L + 1);
+        comparisons += 2.0 * na * (mode == COLS_FULL ? ctx->h_cum_n[(size_t)n] : mode == COLS_DIAGONAL ? na : ctx->h_cum_n[(size_t)rows[i] + 1]);
+    }
+    out.write_all = mode == COLS_FULL ? 1 : 0;
+
+    /* W = 10 words per lane; W = 20 was measured too (config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms):
+     * the longer per-shift chain does not pay for the registers it costs */
+    bs_kernel_t bs10 = nullptr;
+    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = gkm_pick_bitslice(2, L, d);
+    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs10)
+        return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
+    if (!bitslice_serves(ctx)) bs10 = nullptr; /* auto: the general kernel where it is the faster one */
+
+    if (bs10) {
+        /* pack the rows into lanes at bit-row granularity (gkm_pack.h) */
+        std::vector<int> nwin((size_t)nrows);
+        for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
+        /* At most 64 rows per tile unless that leaves lanes empty (rows shorter than half a lane): the
+         * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
+        gkmpack::Packing pk = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, 64);
+        int slots = 64;
+        {
+            gkmpack::Packing wide = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, gkmpack::MAX_ROWS);
+            if (getenv("GKM_FORCE_PACKED") ? !strcmp(getenv("GKM_FORCE_PACKED"), "128")
+                                           : (double)pk.ntiles > 1.04 * (double)wide.ntiles) {
+                pk = std::move(wide);
+                slots = gkmpack::MAX_ROWS;
+            }
+        }
+        const int W = pk.W, ntiles = pk.ntiles;
+        /* no lane with a second piece -> the leaner kernel variant */
+        bool packed = getenv("GKM_FORCE_PACKED") != nullptr || slots != 64;
+        for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
+        const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
+        bs_kernel_t bs = !packed ? gkm_pick_bitslice(0, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
+        /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
+        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
+        /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
+         * kernel depend on its occupancy? */
+        const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t) + lds_pad;
+        bool bperm = false;
+        if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
+            hipFuncAttributes fa, fb;
+            const char *force = getenv("GKM_FORCE_BPERM");
+            bs_kernel_t bsp = gkm_pick_bitslice(3, L, d);
+            auto granules = [](size_t bytes) { return (bytes + 1279) / 1280; };
+            if (force ? atoi(force) != 0
+                      : (hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess &&
+                         hipFuncGetAttributes(&fb, (const void *)bsp) == hipSuccess &&
+                         granules(fa.sharedSizeBytes + dyn_lds) > granules(fb.sharedSizeBytes + dyn_lds)))
+                bperm = true;
+            if (bperm) bs = bsp;
+        }
+        const size_t nl = (size_t)ntiles * 64;
+        std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
+        std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)LPW, 0u);
+        std::vector<int> fill(nl, 0);
+        for (const gkmpack::Piece &pc : pk.pieces) {
+            const int k = fill[(size_t)pc.lane]++;
+            int *dd = &desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
+            dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
+            lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
+            /* byte offset of the row slot in accl[m][.]; the row l-mer at lane position i0 is |c0 - i0| l-mers
+             * away from its sequence's centre l-mer, c0 > -2048 is stored with a bias of 2048 so that the
+             * kernel's unsigned |a - b| applies */
+            /* second profile copy (k_gram_bitslice two_copies): odd lanes of a tile with at most slots / 2 rows */
+            const int tile_of = pc.lane / 64;
+            const bool second = 2 * pk.tile_nrows[(size_t)tile_of] <= slots && (pc.lane & 1);
+            const uint32_t slot4 = ((uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u)) * 4u;
+            const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
+            if (packed) {
+                lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
+            } else {
+                lane_piece[(size_t)pc.lane * 2] = slot4;
+                lane_piece[(size_t)pc.lane * 2 + 1] = c0b;
+            }
+        }
+        /* columns [cbeg, cend) per tile */
+        std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
+        std::vector<int64_t> soff((size_t)ntiles + 1, 0);
+        for (int t = 0; t < ntiles; t++) {
+            int amin = n;
+            for (int rs = 0; rs < pk.tile_nrows[(size_t)t]; rs++) amin = std::min(amin, pk.tile_row[(size_t)t * gkmpack::MAX_ROWS + rs]);
+            cbeg[(size_t)t] = mode == COLS_DIAGONAL ? amin : 0;
+            cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
+            soff[(size_t)t + 1] = soff[(size_t)t] + (cend[(size_t)t] - cbeg[(size_t)t]);
+        }
+        if (soff[(size_t)ntiles] <= 0 || soff[(size_t)ntiles] > 0x7fffffffLL) return set_err_msg("gram: bad work item count", 2);
+
+        /* every per-launch table goes to the device in ONE copy (the boundary call issues 13 launches) */
+        std::vector<char> blob;
+        auto put = [&](const void *src, size_t bytes) {
+            const size_t at = (blob.size() + 255) & ~(size_t)255;
+            blob.resize(at + bytes);
+            memcpy(blob.data() + at, src, bytes);
+            return at;
+        };
+        const size_t o_desc = put(desc.data(), desc.size() * sizeof(int));
+        const size_t o_mask = put(lane_mask.data(), nl * sizeof(uint32_t));
+        const size_t o_piece = put(lane_piece.data(), lane_piece.size() * sizeof(uint32_t));
+        const size_t o_trow = put(pk.tile_row.data(), pk.tile_row.size() * sizeof(int));
+        const size_t o_tout = put(pk.tile_out.data(), pk.tile_out.size() * sizeof(int));
+        const size_t o_tn = put(pk.tile_nrows.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_cbeg = put(cbeg.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
+        const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
+        const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
+        /* work-item order: (column chunk, tile) entries (BsArgs) where that is free.  Measured (tools/col_chunk_sweep2.sh,
+         * profiles/r4_col_chunk_sweep.txt; kernel ms / GB read from L2 misses per launch): config 2 plain order 72.4 / 5.48,
+         * chunks of 4 096 columns 72.5 / 0.19 -- the column tables (5.3 KB per 300-bp column) of a chunk, dealt over the 8
+         * XCDs, are 2.7 MB per L2 and stay there; config 5 151.2 / 12.1 against 151.8 / 2.3; gkmQC's shape (10.3 KB per
+         * column) 384.1 / 28.7 against 385.4 / 21.9 at 4 096 (5.3 MB per L2: no reuse) and 386.4 / 4.2 at 2 560.  SMALLER
+         * chunks cost time: the 28 waves of a CU then belong to 3-5 tiles instead of 1-2 and their hit paths evict each
+         * other's packed rows from the 32 KB L1 (1 024 columns: +2 % on config 2, +6 % on the other two).  The traffic
+         * binds nothing (80 GB/s against 8 TB/s), the kernel's time is what counts: chunks of 4 096 columns where a chunk's
+         * tables fit 3 MB per XCD (config 2, config 3), the plain tile-major order everywhere else.  GKM_COL_CHUNK=<columns>
+         * overrides, 0 = plain. */
+        std::vector<int64_t> ent_off;
+        std::vector<int> ent_tile, ent_j0, ent_j1;
+        int64_t n_items = soff[(size_t)ntiles];
+        {
+            const double mean_len = ctx->h_cum_n[(size_t)n] / n + (L - 1);
+            const double col_bytes = (4.0 * (mean_len + W) + 2.0 * (mean_len / 16.0 + 1.0)) * sizeof(uint32_t);
+            long chunk = col_bytes * 4096.0 / 8.0 <= 3.0 * 1048576.0 ? 4096 : 0;
+            if (const char *cc = getenv("GKM_COL_CHUNK")) chunk = atol(cc) & ~7L;
+            if (chunk >= 8 && chunk < n) {
+                int64_t at = 0;
+                for (long c0 = 0; c0 < n; c0 += chunk)
+                    for (int t = 0; t < ntiles; t++) {
+                        const int j0 = std::max<long>(cbeg[(size_t)t], c0), j1 = (int)std::min<long>(cend[(size_t)t], c0 + chunk);
+                        if (j0 >= j1) continue;
+                        ent_off.push_back(at);
+                        ent_tile.push_back(t);
+                        ent_j0.push_back(j0);
+                        ent_j1.push_back(j1);
+                        at += (j1 - j0 + 7) & ~7;
+                    }
+                ent_off.push_back(at);
+                if (at > 0x7fffffffLL) { ent_off.clear(); ent_tile.clear(); } /* (too many items with the padding: plain order) */
+                else n_items = at;
+            }
+        }
+        const int nent = (int)ent_tile.size();
+        const size_t o_eoff = nent ? put(ent_off.data(), ent_off.size() * sizeof(int64_t)) : 0;
+        const size_t o_etile = nent ? put(ent_tile.data(), (size_t)nent * sizeof(int)) : 0;
+        const size_t o_ej0 = nent ? put(ent_j0.data(), (size_t)nent * sizeof(int)) : 0;
+        const size_t o_ej1 = nent ? put(ent_j1.data(), (size_t)nent * sizeof(int)) : 0;
+        const int NS = slots;
+        auto &scr = ctx->scratch[ctx->sel];
+        /* (The tables and row planes on a second stream and untile on a third, so that the Gram kernels of the drop-in
+         * call's row blocks follow each other with nothing in between, was built and measured in round 4: k_untile's
+         * 33 KB workgroups then wait for room beside the next block's Gram kernel -- its 28 waves per CU leave 17 KB of
+         * LDS -- and finish only when it does; the copies start one block late: 90.6 instead of 81.4 ms for the call.) */
+        /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
+         * so that the lane field of a record's origin word is the lane's byte offset (gkm_bitslice.h pack_meta) */
+        const int rpw = 32;
+        static_assert(32 * 10 / 16 + 1 <= 32, "a lane's packed positions fit 128 bytes");
+        PinBuf *hb = pin_acquire(blob.size());
+        if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
+        if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) ||
+            scr.rowpk.ensure(nl * (size_t)rpw, true) ||
+            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS, true))) {
+            pin_release(hb);
+            return 4;
+        }
+        /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
+         * may still be reading it after this function has returned and freed it */
+        memcpy(hb->p, blob.data(), blob.size());
+        {
+            hipError_t ce = hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream);
+            if (ce == hipSuccess && hipLaunchHostFunc(stream, pin_release, hb) != hipSuccess) {
+                ce = hipStreamSynchronize(stream); /* no host function: hand the buffer back once the copy is over */
+                pin_release(hb);
+            } else if (ce != hipSuccess) {
+                pin_release(hb);
+            }
+            HIPCHK(ce);
+        }
+        char *tb = scr.tables.p;
+        static_assert(10 * 4 >= 32, "plane 3: ten parts of four packed words cover the lane's 32");
+        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4, (unsigned)W), dim3(64), 0, stream, ctx->codes.p,
+                           ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
+        HIPCHK(hipGetLastError());
+
+        BsArgs A;
+        A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
+        A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
+        A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
+        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd32 = (const uint32_t *)ctx->wd.p;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4;
+        A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
+        A.len = ctx->len.p;
+        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+        A.out = out;
+        if (out.row_off) A.out.row_off = (const int64_t *)(tb + o_roff);
+        A.ntiles = ntiles;
+        A.S = out.G ? scr.S.p : nullptr;
+        A.tile_soff = (const int64_t *)(tb + o_soff);
+        A.nent = nent;
+        A.ent_off = (const int64_t *)(tb + o_eoff);
+        A.ent_tile = (const int *)(tb + o_etile);
+        A.ent_j0 = (const int *)(tb + o_ej0);
+        A.ent_j1 = (const int *)(tb + o_ej1);
+        /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
+         * the drain at the end of every launch costs -- nothing for one big launch, but the boundary call
+         * issues 13 launches and the multi-GPU path one per chunk. */
+        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipLaunchKernelGGL(bs, dim3((unsigned)n_items), dim3(64), dyn_lds, stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        if (out.G) {
+            int span = 0;
+            for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
+            const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / 64)));
+            if (slots != 64)
+                hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
+                                   A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, A.out);
+            else
+                hipLaunchKernelGGL(k_untile<64>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
+                                   A.tile_nrows, A.tile_row, A.tile_out, A.out);
+            HIPCHK(hipGetLastError());
+        }
+        ctx->last_kernel = bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+    } else {
+        if (ensure_lmers(ctx, stream)) return 4;
+        if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
+        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+        if (out.row_off) {
+            if (ctx->scratch[ctx->sel].rowoff.ensure((size_t)nrows)) return 4;
+            HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rowoff.p, out.row_off, (size_t)nrows * sizeof(int64_t),
+                                  hipMemcpyHostToDevice, stream));
+            out.row_off = ctx->scratch[ctx->sel].rowoff.p;
+        }
+        HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
+        DirectArgs A;
+        A.rows = ctx->scratch[ctx->sel].rows.p; A.nrows = nrows;
+        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
+        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+        A.out = out;
+        A.L = L; A.d = d; A.mode = mode; A.n = n;
+        const unsigned ntiles = (unsigned)((nrows + 63) / 64);
+        int span = 0; /* widest column range of any 64-row tile */
+        double items = 0; /* (tile, column) pairs of the launch */
+        for (unsigned t = 0; t < ntiles; t++) {
+            const int amin = rows[t * 64], amax = rows[std::min<int>((int)t * 64 + 63, nrows - 1)];
+            const int cols = mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1;
+            span = std::max(span, cols);
+            items += cols;
+        }
+        /* columns per workgroup: 16 where that still gives the GPU ~16 waves per SIMD, fewer for small problems (2 000
+         * sequences: 2 000 workgroups of 16 columns left three quarters of the SIMDs idle, 156 ms; now 2 columns) */
+        A.cj = (int)std::min(16.0, std::max(1.0, floor(items / 16384.0)));
+        const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
+        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        ctx->last_kernel = "k_gram_direct";
+    }
+    ctx->ev_valid = true;
+    ctx->last_comparisons = comparisons;
+    return 0;
+}
+
+extern "C" int gkmhip_gram_rows(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                int64_t ld, int32_t *P, int64_t ldp, void *stream_)
+{
+    if (!G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows: bad arguments", 2);
+    if (ld <= rows[nrows - 1]) return set_err_msg("leading dimension too small", 2);
+    GramOut out;
+    out.G = G; out.ld = ld; out.P = P; out.ldp = ldp; out.local_rows = local_rows; out.write_all = 0; out.diag = nullptr; out.row_off = nullptr;
+    return gram_launch(ctx, rows, nrows, COLS_TRIANGLE, out, (hipStream_t)stream_);
+}
+
+extern "C" int gkmhip_gram_rows_packed(gkmhip_ctx *ctx, const int *rows, int nrows, double *G, const int64_t *row_off,
+                                       void *stream_)
+{
+    if (!G || !rows || nrows <= 0 || !row_off) return set_err_msg("gkmhip_gram_rows_packed: bad arguments", 2);
+    for (int i = 0; i < nrows; i++) /* rows may touch (row i ends where row i + 1 starts) but never overlap */
+        if (row_off[i] < 0 || (i + 1 < nrows && row_off[i + 1] < row_off[i] + (int64_t)rows[i] + 1))
+            return set_err_msg("gkmhip_gram_rows_packed: row offsets must leave rows[i] + 1 doubles per row", 2);
+    GramOut out;
+    out.G = G; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 1; out.write_all = 0; out.diag = nullptr;
+    out.row_off = row_off;
+    return gram_launch(ctx, rows, nrows, COLS_TRIANGLE, out, (hipStream_t)stream_);
+}
+
+extern "C" int gkmhip_gram_rows_full(gkmhip_ctx *ctx, const int *rows, int nrows, int local_rows, double *G,
+                                     int64_t ld, void *stream_)
+{
+    if (!ctx || !G || !rows || nrows <= 0) return set_err_msg("gkmhip_gram_rows_full: bad arguments", 2);
+    if (ld < ctx->n) return set_err_msg("leading dimension too small", 2);
+    GramOut out;
+    out.G = G; out.ld = ld; out.P = nullptr; out.ldp = 0; out.local_rows = local_rows; out.write_all = 1; out.diag = nullptr; out.row_off = nullptr;
+    return gram_launch(ctx, rows, nrows, COLS_FULL, out, (hipStream_t)stream_);
+}
+
+__global__ void k_sqrt_inplace(double *__restrict__ v, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = sqrt(v[i]); /* libgkm.c:753-758 */
+}
+
+extern "C" int gkmhip_self_norms(gkmhip_ctx *ctx, double *sqnorm, void *stream_)
+{
+    if (!ctx || !sqnorm || ctx->n <= 0) return set_err_msg("gkmhip_self_norms: bad arguments", 2);
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<int> all((size_t)ctx->n);
+    for (int i = 0; i < ctx->n; i++) all[(size_t)i] = i;
+    GramOut out;
+    out.G = nullptr; out.ld = 0; out.P = nullptr; out.ldp = 0; out.local_rows = 0; out.write_all = 0; out.diag = sqnorm; out.row_off = nullptr;
+    const int rc = gram_launch(ctx, all.data(), ctx->n, COLS_DIAGONAL, out, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sqrt_inplace, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, stream, sqnorm, ctx->n);
+    HIPCHK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,453 @@
+/*
+ * gkm_gram_bitslice.hip -- the HOT kernel of the gkm kernel-matrix path on MI355X (gfx950): bit-sliced diagonal mismatch
+ * profiles -> raw Gram values, tile-transposed (replaces the k-mer tree DFS of src/libgkm.c:315-387
+ * and the per-row reduction of :553-589).  Written for CDNA4 only: 64-wide wavefronts, one wavefront per workgroup, the
+ * column tables streamed through the scalar unit (SGPRs), a per-wave hit list in LDS.  The launch geometry (row packing,
+ * work-item order, tables) is gkm_gram.hip's; the per-lane arithmetic is gkm_bitslice.h's (unit-tested on the CPU).
+ */
+#include "gkm_gram_bitslice.h"
+
+/* wave64 inclusive prefix sum on the DPP network (no LDS round trips): four row_shr steps
+ * scan each row of 16 lanes, row_bcast:15 / row_bcast:31 carry the row totals across */
+__device__ __forceinline__ int wave_inclusive_scan(int x)
+{
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, true); /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, true); /* row_shr:2 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, true); /* row_shr:4 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, true); /* row_shr:8 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false); /* row_bcast:15 -> rows 1,3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false); /* row_bcast:31 -> rows 2,3 */
+    return x;
+}
+
+/* position of the lowest set bit, 0xFFFFFFFF for 0 (v_ffbl_b32's own convention; __builtin_ctz(0) is
+ * undefined and the generic cttz costs a second instruction) */
+__device__ __forceinline__ uint32_t ffbl_or_ones(uint32_t x)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* 2 x as an addition: on gfx950 v_lshlrev_b32 issues at HALF the rate of v_add_u32 (tools/valu_ops.hip), and hipcc
+ * turns x + x back into a shift */
+__device__ __forceinline__ uint32_t twice(uint32_t x)
+{
+    uint32_t r;
+    asm("v_add_u32 %0, %1, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+/* popcount(x) + acc in one instruction (hipcc sums separate popcounts with extra adds) */
+__device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc)
+{
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+#ifndef GKM_BS_GRP
+#define GKM_BS_GRP 5 /* config 2 / gkmQC's default L=10 k=6 d=3: 2 -> 89.8 / 118.1 ms, 5 -> 81.0 / 119.3, 10 -> 87.5 / 138.3 */
+#endif
+constexpr int BS_GRP = GKM_BS_GRP;     /* hit words per list record: the lanes are compacted once per BS_GRP words */
+#ifndef GKM_BS_TRIP
+#define GKM_BS_TRIP 64 /* config 2: 64 -> 87.2 ms (ring of 128: index wrap is one AND), 128 -> 89.1, 192 -> 97.3 */
+#endif
+constexpr int BS_TRIP = GKM_BS_TRIP; /* records resolved per trip: one per lane */
+static_assert(BS_TRIP == 64, "a trip resolves one record per lane");
+/* records the wave-wide hit list holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
+constexpr int BS_CAP = BS_TRIP + 64;
+#ifndef GKM_BS_WAVES
+#define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
+                          config 2 with the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 */
+#endif
+#ifndef GKM_BS_PACKED_WAVES
+#define GKM_BS_PACKED_WAVES 6 /* several-pieces-per-lane kernels: 75-78 VGPRs */
+#endif
+#ifndef GKM_TRIP_PRIO
+#define GKM_TRIP_PRIO 3 /* wave priority (s_setprio, 0..3) inside a trip; 0 = as rounds 1-3 */
+#endif
+
+/*
+ * One wavefront = 64 row segments (one per lane) x ONE column sequence.
+ * For both strands of the column the wave sweeps all T cyclic shifts; per shift each lane
+ * evaluates 32*W l-mer window comparisons with ~13 VALU instructions per 32 (gkm_bitslice.h).
+ * Hit words are parked, compacted over the lanes, in a wave-wide LDS list (a stack) of records and turned
+ * into weighted profile counts in full-wave batches, so the hot loop has no data-dependent
+ * control flow besides the push.
+ */
+template <int W, int L, int D, int PK>
+__global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+{
+    /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
+     *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
+     *      3: as 0, but a trip fetches the source lane's piece entry from that lane's registers (ds_bpermute_b32)
+     *         instead of a 512-byte table in LDS -- taken when those 512 bytes cost an LDS allocation granule,
+     *         i.e. waves per CU (rows and columns of 600 bp: 24 -> 32 one-wave workgroups per CU by LDS, 449 -> 436 ms
+     *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
+    constexpr bool PACKED = PK == 1 || PK == 2;
+    constexpr bool BPERM = PK == 3;
+    /* (The ablation builds of rounds 1-3 -- parts of this kernel skipped to time the rest, results wrong -- lived
+     * here as a fifth template parameter; they are gone from the source since round 4.  tools/variants.sh rebuilds
+     * them from revision a4bed73, profiles/r2_ablation_timings.txt and r2_pmc_ablation_builds*.txt hold what they
+     * measured.) */
+    using namespace gkmbs;
+    /* LDS per wave: 3 KB hit list + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
+     * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
+     * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
+     * of the row lane's packed positions from global memory (8 KB per tile -- 128 bytes per lane, of which 84 are
+     * used -- L1 resident: the waves of a CU work on the same tile). */
+    extern __shared__ uint32_t s_dyn[]; /* [wd_words] weight bytes, then [2 * pkw] column strands (forward, reverse complement) */
+    /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
+     * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
+     * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
+     * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
+     * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
+    __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
+    /* (array BS_GRP of s_list: first word of the group, delta, strand, row lane) */
+    /* PACKED: lanes may hold several pieces (gkm_pack.h).  When no lane of the call holds more than one
+     * piece (e.g. every fixed-length data set) the leaner variant runs: one (slot, centre) pair per lane.
+     * The several-pieces variant exists for 64 and for 128 row slots per tile: the profiles of 128 slots
+     * (2.5 KB at d = 4) cost a wave per SIMD, so the host packs at most 64 rows into a tile unless
+     * that would leave lanes empty (many rows shorter than half a lane).  LDS per wave, d = 4, 600 bp:
+     * 3 KB ring + 0.25 KB piece starts + 1 KB piece table + 1.25 KB profiles + 0.6 KB strands and weights
+     * = 6.1 KB -> 6 waves per SIMD (8.4 KB -> 4.75 with 128 slots and two-word piece entries). */
+    constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
+    constexpr int NSLOT = PK == 2 ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
+    __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
+    /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
+     * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
+    __shared__ uint32_t lpiece[PACKED ? 64 * NP : BPERM ? 1 : 128];
+    __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
+    static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
+    /* The list is a STACK (round 3; a ring before): a trip is due as soon as it holds BS_TRIP records and it is checked
+     * after every group (at most 64 new records); a trip takes the BS_TRIP records on TOP and puts at most as many back:
+     * the list never holds more than BS_TRIP + 63 records.  The order in which hits are resolved is immaterial
+     * (integer adds), and a stack needs no head and no wrap: one AND less per push, per trip and per re-push, and the
+     * trip's read address is lane * 4 + a scalar. */
+    static_assert(BS_CAP >= BS_TRIP + 64 && BS_CAP % 64 == 0, "hit list too small");
+    static_assert(gkmpack::MAX_ROWS % 64 == 0, "row slots are finished 64 at a time");
+
+    const int lane = threadIdx.x;
+    /* (raising the priority of a NEW wave too, until its row planes are loaded, was measured: 395.4 against 388.9 ms on
+     * gkmQC's shape, nothing on config 2 -- profiles/r4_kernel_ab_trip_priority.txt) */
+    /* block -> (tile, column): see BsArgs.  All of this is wave-uniform (scalar loads, SALU). */
+    int tile, j0;
+    if (A.nent > 0) { /* (chunk, tile) entries: largest e with ent_off[e] <= blockIdx.x */
+        int lo = 0, hi = A.nent;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.ent_off[mid] <= (int64_t)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        tile = A.ent_tile[lo];
+        j0 = A.ent_j0[lo] + (int)((int64_t)blockIdx.x - A.ent_off[lo]);
+        if (j0 >= A.ent_j1[lo]) return; /* padding item */
+    } else {
+        int lo = 0, hi = A.ntiles; /* largest tile with tile_soff[tile] <= blockIdx.x */
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (A.tile_soff[mid] <= (int64_t)blockIdx.x) lo = mid;
+            else hi = mid;
+        }
+        tile = lo;
+        j0 = A.tile_cbeg[tile] + (int)((int64_t)blockIdx.x - A.tile_soff[tile]);
+    }
+    const int j1 = j0 + 1;
+    const int nrows = A.tile_nrows[tile];
+    constexpr int NE = NSLOT / 64; /* row slots a lane finishes in the epilogue */
+    /* A tile with at most NSLOT / 2 rows (600-bp rows: 32 per tile) keeps TWO copies of every profile, NSLOT / 2 slots
+     * apart, and the epilogue adds them: the hits of odd source lanes go to the second copy (the host puts the offset
+     * into those lanes' piece entries, gram_launch), so the ds_add_u32 of a trip spread over twice the addresses --
+     * 88 % of all hits have m = d and 64 lanes were adding into 32 words. */
+    const bool two_copies = 2 * nrows <= NSLOT;
+
+    uint32_t Ahi[W], Alo[W], AV[W];
+#pragma unroll
+    for (int w = 0; w < W; w++) {
+        Ahi[w] = A.rowplanes[(((size_t)tile * 3 + 0) * W + w) * 64 + lane];
+        Alo[w] = A.rowplanes[(((size_t)tile * 3 + 1) * W + w) * 64 + lane];
+        AV[w] = A.rowplanes[(((size_t)tile * 3 + 2) * W + w) * 64 + lane];
+    }
+
+    /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
+    if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
+    constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
+    if (!BPERM) {
+#pragma unroll
+        for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
+    }
+    /* BPERM: the lane keeps its own (row slot * 4, biased centre offset) in two registers and a trip fetches
+     * the source lane's pair over the permute network (ds_bpermute_b32: no LDS storage, no bank conflicts).
+     * The 512 bytes this takes out of LDS bring a wave under 5 120 bytes = 4 allocation granules of 1 280
+     * (tools/lds_occupancy.hip): 32 instead of 24 one-wave workgroups fit a CU at 600 bp. */
+    uint32_t my_both = 0u; /* row slot * 4 (< 256) | biased centre offset (< 8192) << 16 */
+    if (BPERM)
+        my_both = A.lane_piece[(size_t)(tile * 64 + lane) * 2] | (A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1] << 16);
+    const uint32_t lane_tag = (uint32_t)lane << META_LANE_SHIFT, lane4 = (uint32_t)lane << 2;
+    const int pkw = A.pkw;
+    /* dynamic LDS: the column's two packed strands first, interleaved word by word (their address is then a constant
+     * of the kernel and folds into the offset field of the reads), the weight table behind them (its offset rides in
+     * the third operand of the v_sad_u32 that forms the index) */
+    uint32_t *const s_col = s_dyn;
+    /* byte offset of the weight table, kept in a VGPR: the column-side index |q - centre| + wbase would otherwise name
+     * two SGPRs in one v_sad_u32 (one is the limit) and cost a v_mov per hit */
+    uint32_t wbase;
+    asm volatile("v_mov_b32 %0, %1" : "=v"(wbase) : "s"((uint32_t)pkw * 8u));
+    for (int x = lane; x < A.wd_words; x += 64) s_dyn[2 * pkw + x] = A.wd32[x];
+    /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
+     * base instead of a 64-bit address computed per lane); 128 bytes per lane, so that the lane field of a
+     * record's origin word IS the lane's byte offset */
+    const char *const rowpk_tile = (const char *)(A.rowpk + (size_t)tile * 64 * A.rpw);
+
+    for (int j = j0; j < j1; j++) {
+        const int T = A.len[j];
+        const int nB = T - L + 1;
+        const uint32_t rcpT = mod_magic((uint32_t)T);
+        for (int x = lane; x < 2 * pkw; x += 64) s_col[x] = A.colpk[(size_t)j * 2 * pkw + x];
+        /* weight of a column l-mer q: forward strand wd[|nB/2 - q|]; reverse strand wt_rc[q] = wt[nB-1-q]
+         * (libgkm.c:924) = wd[|nB/2 - (nB-1-q)|] = wd[|q + [nB even] - nB/2|]; the [nB even] of the reverse strand
+         * travels in bit 5 of the record's origin word (pack_meta) */
+        const uint32_t ccen = (uint32_t)(nB / 2);
+        const int ceven = (nB & 1) ? 0 : 1;
+#pragma unroll
+        for (int m = 0; m <= D; m++)
+            for (int rs = lane; rs < (two_copies ? NSLOT : nrows); rs += 64) accl[m * NSLOT + rs] = 0u;
+        int s_n = 0; /* records in the hit list (wave-uniform) */
+
+        /* One hit -> accl[m][row slot] += wa * wb.  (meta + sel, bit) name the row lane r, the lane position
+         * i0 = bit*W + w of the window, the shift and the strand; lane and bit row name the piece (gkm_pack.h),
+         * the piece names the row slot and c0, which makes |c0 - i0| the row l-mer's distance to its sequence's
+         * centre l-mer (libgkm.c:912-925 depends on nothing else).  Written for the ISSUE COST -- the kernel is
+         * bound by VALU issue, and on gfx950 only the plain two-operand integer operations and v_bitop3_b32 issue
+         * at the full rate; v_bfe, v_mad_u32_u24, v_min, v_sad, v_alignbit, v_ffbl, v_bcnt, compares, SDWA and
+         * anything with an SGPR operand take twice as long (tools/valu_ops.hip).  Hence the layout of the origin
+         * word (gkm_bitslice.h pack_meta: fields that are masked in place or shifted out of the top), 128 bytes per
+         * lane of packed positions, the column's strands interleaved word by word, (a & const) | b as one
+         * v_bitop3_b32, the weight table's LDS offset as the third operand of the v_sad_u32 that forms the index.
+         * Same arithmetic as resolve_hit_packed (gkm_bitslice.h), which the CPU tests run against the oracle. */
+        auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
+            const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
+            const int k = PACKED ? piece_of_bitrow(*(const uint32_t *)((const char *)lmask + (PACKED ? (lane128 >> 5) : 0u)), (int)bit) : 0;
+            uint32_t slot4, c0b; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
+            if (PACKED) {
+                static_assert(!PACKED || NP == 4, "lpiece is addressed as lane * 16 + piece * 4");
+                const uint32_t lp = *(const uint32_t *)((const char *)lpiece + ((lane128 >> 3) + ((uint32_t)k << 2)));
+                slot4 = lp & 0xFFFFu;
+                c0b = lp >> 16;
+            } else if (BPERM) {
+                slot4 = pslot4;
+                c0b = pc0b;
+            } else {
+                const uint32_t *lp2 = (const uint32_t *)((const char *)lpiece + (lane128 >> 4));
+                slot4 = lp2[0];
+                c0b = lp2[1];
+            }
+            const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 15u);
+            const uint32_t x = i0 + (ms >> 21);
+            uint32_t q;
+            if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
+            else q = mod_small(x, (uint32_t)T, rcpT);
+            /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
+            if ((int)q < nB) {
+                /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
+                const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+                const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, (ms >> 2) & 4u));
+                const uint8_t *wdb = (const uint8_t *)s_dyn;
+                const uint32_t wa = wdb[__usad(c0b, i0 | 2048u, wbase)];
+                const uint32_t wb = wdb[__usad(q + ((ms >> 5) & 1u), ccen, wbase)];
+                /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
+                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
+                const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
+                const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
+                if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 */
+                    atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+            }
+        };
+
+        /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
+        auto trip = [&](auto partial_tag, int c) {
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            /* A wave inside a trip issues AHEAD of the waves that are in the counting loop (s_setprio; back to 0 at the
+             * end of the trip).  A trip is a chain of short instruction runs between LDS and memory round trips (record
+             * -> piece entry -> row words -> column words and weights -> accumulate); at equal priority each run waits
+             * its turn behind six waves of straight-line counting code, and the chain -- with the LDS list and the other
+             * lanes' hits waiting on it -- stretches.  Round 4, same-run A/B (profiles/r4_kernel_ab_trip_priority.txt):
+             * config 2 75.2 -> 72.8 ms, gkmQC's own shape 433.3 -> 396.0 ms, config 5 167.4 -> 152.7 ms; priority 1 and
+             * 3 do the same.  The total VALU work is unchanged: this is issue ORDER, not instruction count. */
+            __builtin_amdgcn_s_setprio(GKM_TRIP_PRIO);
+            /* the c records on top: lane * 4 + a scalar (kept apart from the lane term: hipcc would fuse the shift into a
+             * half-rate v_lshl_add_u32 and split the reads around a negative offset) */
+            const uint32_t top4 = (uint32_t)__builtin_amdgcn_readfirstlane((s_n - c) << 2);
+            uint32_t at_off;
+            asm("v_add_u32 %0, %1, %2" : "=v"(at_off) : "s"(top4), "v"(lane4));
+            const char *const at = (const char *)s_list + at_off;
+            uint32_t h[BS_GRP];
+            /* (every ring slot is readable: the lanes past the end of a short, final trip are
+             * cleared afterwards instead of being masked out of the loads) */
+#pragma unroll
+            for (int g = 0; g < BS_GRP; g++) h[g] = *(const uint32_t *)(at + g * BS_CAP * 4);
+            const uint32_t meta = *(const uint32_t *)(at + BS_GRP * BS_CAP * 4);
+            if (PARTIAL) {
+#pragma unroll
+                for (int g = 0; g < BS_GRP; g++) h[g] = (lane < c) ? h[g] : 0u;
+            }
+            uint32_t first = ffbl_or_ones(h[0]), total = 0u;
+#pragma unroll
+            for (int g = 1; g < BS_GRP; g++) first = min(first, ffbl_or_ones(h[g]) | (uint32_t)(g << 5));
+#pragma unroll
+            for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
+            const uint32_t sel = first >> 5, bit = first & 31u;
+            const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 4 bits */
+            uint32_t pslot4 = 0u, pc0b = 0u;
+            if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
+                const int from = (int)((ms >> (META_LANE_SHIFT - 2)) & 0xFCu); /* source lane * 4 */
+                /* ONE permute of (slot * 4 | c0b << 16) and two full-rate VALU operations to take it apart, not two
+                 * permutes: the LDS pipe is busy two thirds of the time on gkmQC's shape (SQ_LDS_IDX_ACTIVE per CU against
+                 * the kernel's cycles, profiles/r4_pmc_peaks.json): 392.6 -> 388.6 ms (profiles/r4_kernel_ab_trip_priority.txt) */
+                const uint32_t both = (uint32_t)__builtin_amdgcn_ds_bpermute(from, (int)my_both);
+                pslot4 = both & 0xFFFFu;
+                pc0b = both >> 16;
+            }
+            /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
+            if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
+            s_n -= c;
+            const unsigned long long more = __ballot(total > 1u);
+            if (more) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                if (total > 1u) {
+                    char *const to = (char *)s_list + ((rank + (uint32_t)s_n) << 2);
+#pragma unroll
+                    for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
+                    *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
+                    atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
+                }
+                s_n += (int)__popcll(more);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+        /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
+         * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
+         * again.  Fewer than one trip's worth of records waits in the list; the last call of a column
+         * (final) empties it.
+         * No select chains: the position of the first hit is min over the words of ffbl(word) | 32 g
+         * (v_ffbl_b32 gives all ones for an empty word, so empty words lose the min), the number of
+         * hits left is a popcount sum, and a record that goes back to the list is copied unchanged and
+         * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
+        auto trips = [&](bool final) {
+            while (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
+            if (final)
+                while (s_n > 0) {
+                    if (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
+                    else trip(std::true_type(), s_n);
+                }
+        };
+
+        for (int strand = 0; strand < 2; strand++) {
+            /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
+             * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
+            const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
+            const sgpr_words sbl = sbh + A.xw;
+            for (int d0 = 0; d0 < T; d0 += BS_DU) {
+                /* (copying the words to VGPRs once instead of using them as SGPR operands was measured
+                 * slower: 119-129 ms against 111.6 ms on config 2; requesting the next block's words one
+                 * block ahead changes nothing: 92.3 against 92.4 ms) */
+                /* the strand's window-validity plane (third SB plane) is not streamed: wrapped
+                 * windows are rejected when a hit is resolved (gkm_bitslice.h window_hits) */
+                uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];
+#pragma unroll
+                for (int i = 0; i < BS_DU + W - 1; i++) {
+                    bh[i] = sbh[d0 + i];
+                    bl[i] = sbl[d0 + i];
+                }
+#pragma unroll
+                for (int u = 0; u < BS_DU; u++) {
+                    if (d0 + u < T) {
+                        uint32_t hit[W];
+                        window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, (const uint32_t *)nullptr, hit);
+                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand, ceven);
+#pragma unroll
+                        for (int w0 = 0; w0 < W; w0 += BS_GRP) {
+                            /* wave-level compaction at the source, once per group of BS_GRP words: the
+                             * lanes with a hit in the group append (words, origin) to the list at tail
+                             * + their rank among the hit lanes (ballot + mbcnt); EXEC-masked stores, no
+                             * divergent control flow */
+                            uint32_t any = hit[w0];
+#pragma unroll
+                            for (int g = 1; g + 1 < BS_GRP; g += 2) any = lop3<TT_OR3>(any, hit[w0 + g], hit[w0 + g + 1]);
+                            if (BS_GRP % 2 == 0) any |= hit[w0 + BS_GRP - 1];
+                            const unsigned long long mask = __ballot(any != 0u);
+                            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32),
+                                                                            __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+                            if (any != 0u) {
+                                char *const at = (char *)s_list + (((uint32_t)rank + (uint32_t)s_n) << 2);
+#pragma unroll
+                                for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
+                                *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;
+                            }
+                            s_n += (int)__popcll(mask);
+                            if (s_n >= BS_TRIP) trips(false);
+                        }
+                    }
+                }
+            }
+        }
+        trips(true);
+
+        /* epilogue: one lane per row slot of the tile */
+#pragma unroll
+        for (int k = 0; k < NE; k++) {
+            /* (row and output row of the slot are read here, not kept in registers through the sweep) */
+            const int rs = k * 64 + lane;
+            const int row = rs < nrows ? A.tile_row[tile * gkmpack::MAX_ROWS + rs] : -1;
+            if (row < 0 || (j > row && !A.out.write_all)) continue;
+            /* the profile: both copies where there are two (uint32 addition: the int32 wrap-around of the
+             * reference's accumulator, libgkm.c:338, is kept) */
+            uint32_t prof[D + 1];
+#pragma unroll
+            for (int m = 0; m <= D; m++) prof[m] = accl[m * NSLOT + rs] + (two_copies ? accl[m * NSLOT + rs + NSLOT / 2] : 0u);
+            /* sum_m c_m P_m in ascending m from 0.0 (libgkm.c:576-582) */
+            double g = 0.0;
+#pragma unroll
+            for (int m = 0; m <= D; m++) g += A.c[m] * (double)(int32_t)prof[m];
+            const int64_t r = A.out.local_rows ? A.tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
+            if (A.out.diag && j == row) A.out.diag[row] = g;
+            if (A.S) A.S[(A.tile_soff[tile] + (j - A.tile_cbeg[tile])) * NSLOT + rs] = g;
+            if (A.out.P) {
+#pragma unroll
+                for (int m = 0; m <= D; m++)
+                    A.out.P[(r * A.out.ldp + j) * (D + 1) + m] = (int32_t)prof[m];
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------- the instantiation table */
+template <int W, int PACKED>
+static bs_kernel_t pick_bitslice(int L, int d)
+{
+#define GKM_BS(LL, DD) \
+    if (L == LL && d == DD) return k_gram_bitslice<W, LL, DD, PACKED>;
+    /* every (L, d) with 3 <= L <= 12, d <= min(4, L - 1) (what bin/gkmqc.py:185 can ask for), plus the d > 4 pairs
+     * where this kernel beats k_gram_direct -- see auto_takes_bitslice() below for where that is. */
+#define GKM_BS_L(LL) GKM_BS(LL, 0) GKM_BS(LL, 1) GKM_BS(LL, 2) GKM_BS(LL, 3) GKM_BS(LL, 4)
+    GKM_BS(3, 0) GKM_BS(3, 1) GKM_BS(3, 2)
+    GKM_BS(4, 0) GKM_BS(4, 1) GKM_BS(4, 2) GKM_BS(4, 3)
+    GKM_BS_L(5) GKM_BS_L(6) GKM_BS_L(7) GKM_BS_L(8) GKM_BS_L(9) GKM_BS_L(10) GKM_BS_L(11) GKM_BS_L(12)
+    GKM_BS(11, 5) GKM_BS(12, 5) GKM_BS(12, 6)
+#undef GKM_BS_L
+#undef GKM_BS
+    return nullptr;
+}
+
+bs_kernel_t gkm_pick_bitslice(int pk, int L, int d)
+{
+    switch (pk) {
+    case 0: return pick_bitslice<10, 0>(L, d);
+    case 1: return pick_bitslice<10, 1>(L, d);
+    case 2: return pick_bitslice<10, 2>(L, d);
+    case 3: return pick_bitslice<10, 3>(L, d);
+    }
+    return nullptr;
+}

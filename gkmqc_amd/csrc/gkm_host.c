@@ -5,7 +5,7 @@
  * These are tiny tables and a ~3 MB text parse; they stay on the host because
  * floor(M*exp(..)+1) and the c_m recurrences must come from the host libm to be
  * bit-identical with the reference.  Everything heavy is in
- * gkm_device.hip.
+ * gkm_context.hip ... gkm_copyout.hip (gkm_internal.h).
  */
 #include "gkm_host.h"
 

@@ -264,7 +264,7 @@ def test_merge_of_the_two_assemblies():
 
 def test_committed_pmc_summaries_match_the_kernel_source():
     """The line's roofline.frac comes from profiles/r*_pmc_<workload>.json, which bench.py accepts only if it was taken
-    on THIS kernel source (SHA-256 of gkm_device.hip, gkm_bitslice.h, gkm_pack.h).  An edit to those files after the last
+    on THIS kernel source (SHA-256 of bench.KERNEL_SOURCES: the hot kernel, its headers, the launch geometry).  An edit to those files after the last
     tools/finalize_r4.sh run would silently turn frac into null in the driver's line: caught here."""
     sys.path.insert(0, ROOT)
     import bench

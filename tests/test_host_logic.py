@@ -161,7 +161,7 @@ def test_no_timing_variants_in_the_product(built):
     found = re.findall(rb"_Z15k_gram_bitsliceILi\d+ELi\d+ELi\d+ELi[0123]E(Li\d+E)?Ev6BsArgs", blob)
     assert len(found) > 100 and set(found) == {b""}, set(found)
     assert b"GKM_VARIANT" not in blob
-    for f in ("gkm_device.hip", "gkm_bitslice.h", "gkm_pack.h"):
+    for f in ("gkm_gram_bitslice.hip", "gkm_gram_bitslice.h", "gkm_gram.hip", "gkm_bitslice.h", "gkm_pack.h"):
         assert "VARIANT" not in open(os.path.join(ROOT, "gkmqc_amd", "csrc", f)).read(), f
 
 
@@ -185,7 +185,7 @@ def test_issue_model_reads_the_hot_kernel(built):
     half-rate opcodes apart from the full-rate ones."""
     import importlib.util
     import shutil
-    obj = os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_device.o")
+    obj = os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_gram_bitslice.o")
     if not (os.path.exists(obj) and shutil.which("llvm-objdump", path="/opt/rocm/lib/llvm/bin")):
         pytest.skip("needs the built device object and llvm-objdump")
     spec = importlib.util.spec_from_file_location("issue_model", os.path.join(ROOT, "tools", "issue_model.py"))

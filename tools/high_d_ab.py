@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Bit-sliced kernel against the general one (k_gram_direct), kernel ms and bit-identity of the matrices, per (L, d) (GPU box):
-how round 4 found the break-even that `auto` now goes by (gkm_device.hip auto_takes_bitslice; profiles/r4_high_d_bitslice_vs_direct.txt).
+how round 4 found the break-even that `auto` now goes by (gkm_gram.hip auto_takes_bitslice; profiles/r4_high_d_bitslice_vs_direct.txt).
 
     python3 tools/high_d_ab.py [--n 2000] [--length 300] [--pairs "10,5 8,4 7,3"]     # pairs of the product's table
     python3 tools/high_d_ab.py --all                                                   # every pair with 5 <= d < L <= 12
 
 Pairs the product does not instantiate need a build whose table holds them:
 
-    tools/build_variant.sh bsx "" HEAD       # then extend pick_bitslice in build_variants/src_bsx/gkmqc_amd/csrc/gkm_device.hip
+    tools/build_variant.sh bsx "" HEAD       # then extend pick_bitslice in build_variants/src_bsx/gkmqc_amd/csrc/gkm_gram_bitslice.hip
                                              # (GKM_BS(L, d) ...) and run that directory's make again
     GKM_LIB_PATH=build_variants/lib_bsx.so python3 tools/high_d_ab.py --all --n 8000
 

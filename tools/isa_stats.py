@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""ISA statistics of the hot instantiations of k_gram_bitslice in a built gkm_device.o (runs where llvm-objdump is):
+"""ISA statistics of the hot instantiations of k_gram_bitslice in a built gkm_gram_bitslice.o (runs where llvm-objdump is):
 VGPRs, SGPRs, scratch, static LDS, instruction counts by class.  Used to show that a refactoring of the kernel
 source left the generated code alone, and to compare experimental builds.
 
-    python3 tools/isa_stats.py [--object gkmqc_amd/csrc/build/gkm_device.o] [--kernel W,L,D,PK ...] [--dump DIR]
+    python3 tools/isa_stats.py [--object gkmqc_amd/csrc/build/gkm_gram_bitslice.o] [--kernel W,L,D,PK ...] [--dump DIR]
 """
 import argparse
 import os
@@ -58,7 +58,7 @@ def stats(elf, sym):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--object", default=os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_device.o"))
+    ap.add_argument("--object", default=os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_gram_bitslice.o"))
     ap.add_argument("--kernel", action="append", help="W,L,D,PK (default: the three hot instantiations)")
     ap.add_argument("--dump", help="directory for the disassembly of each kernel")
     args = ap.parse_args()

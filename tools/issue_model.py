@@ -9,7 +9,7 @@ v_cndmask, SDWA / DPP forms, packed 16-bit operations, and any instruction with 
 VALU instruction with those two rates, and splits the kernel into the counting loop (everything outside the trips,
 per shift) and one trip (between the ring read that precedes the first v_ffbl_b32 and the ds_xor_b32 that ends it).
 
-    python3 tools/issue_model.py [--object gkmqc_amd/csrc/build/gkm_device.o] [--kernel 10,11,3,0] [--shifts-per-block 4]
+    python3 tools/issue_model.py [--object gkmqc_amd/csrc/build/gkm_gram_bitslice.o] [--kernel 10,11,3,0] [--shifts-per-block 4]
         [--waves N --T len --trips N --ms measured]
 
 With --waves/--T/--trips it predicts the kernel time as (shifts x counting cost + trips x trip cost) / (1024 SIMDs x
@@ -160,7 +160,7 @@ def from_pmc(model, pmc, mean_T, kernel_ns):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--object", default=os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_device.o"))
+    ap.add_argument("--object", default=os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_gram_bitslice.o"))
     ap.add_argument("--kernel", default="10,11,3,0", help="W,L,D,PK of the instantiation")
     ap.add_argument("--shifts-per-block", type=int, default=4, help="GKM_BS_DU")
     ap.add_argument("--waves", type=float, default=None)
