@@ -307,7 +307,27 @@ def end_to_end(args, dev):
     out["boundary_first_call_ms"] = walls[0]
     out["boundary_pairs_per_s"] = (n * (n - 1) / 2) / (out["boundary_ms"] * 1e-3)
     assert kmat[n - 1, n - 1] == 1.0 and kmat[n - 1, 0] != 0.0 and kmat[0, n - 1] == 0.0
+    # the gate of `value` on the boundary's matrix too: the cells the call wrote, against the reference's digest
+    out["boundary_parity"] = parity_check(args.workload, args.custom, kmat)
     del kmat, rows
+    # The reference's caller allocates a FRESH zeroed 15 000 x 15 000 matrix for every call (scripts/gkmsvm.py:75-77:
+    # np.zeros, i.e. untouched pages; row r at byte 120 000 r) -- the scatter into it takes the page faults that a reused
+    # matrix (boundary_ms) has already paid.  Timed around the call only, as the caller's own clock would.
+    cap = max(15000, n)
+    fresh = []
+    for _ in range(2):
+        big = np.zeros((cap, cap))
+        rp = (big.ctypes.data + np.arange(cap) * big.strides[0]).astype(np.uintp)
+        t0 = time.perf_counter()
+        rc = device.load().gkm_main_pywrapper(ctypes.byref(opt), rp.ctypes.data, sizes.ctypes.data)
+        fresh.append((time.perf_counter() - t0) * 1e3)
+        assert rc == 0 and int(sizes[0]) == args.n_pos
+        if len(fresh) == 2:
+            out["boundary_fresh_matrix_parity"] = parity_check(args.workload, args.custom, big[:n, :n])
+            out["boundary_fresh_matrix_untouched_outside"] = bool((big[n:] == 0).all() and (big[:n, n:] == 0).all())
+        del big, rp
+    out["boundary_fresh_matrix_ms"] = min(fresh)
+    out["boundary_fresh_matrix_rows"] = cap
     argv = ["-p", pf, "-n", nf, "-w", os.path.join(tmp, "e2e"), "-t", str(args.kernel_type), "-L", str(args.L),
             "-k", str(args.k), "-d", str(args.d), "-s", "1", "-v", "0"]
     walls, auc = [], None
@@ -502,10 +522,17 @@ def launch_ranks(args, argv, cmd=None, timeout=None, capture=None):
         t.join(timeout=5)
     codes = [p.returncode for p in procs]
     # rank 0's line is relayed even when a rank failed: a line whose parity check failed says so itself (exit code 3)
+    text = out0[0].decode() if out0 else ""
+    if why:   # a caller that parses stdout without looking at the exit code must still see that the run failed
+        line = _last_json_line(text)
+        if line is not None and not line.get("parity_failed"):
+            line["ranks_failed"] = True
+            line["ranks_failed_why"] = why
+            text = json.dumps(line) + "\n"
     if capture is not None:      # (run_auto merges rank 0's line with the other assembly's)
-        capture.append(out0[0].decode() if out0 else "")
+        capture.append(text)
     else:
-        sys.stdout.write(out0[0].decode() if out0 else "")
+        sys.stdout.write(text)
         sys.stdout.flush()
     if why:
         sys.stderr.write("bench.py: %s; the other ranks were stopped (exit codes %s)\n" % (why, codes))
@@ -588,23 +615,49 @@ def brief_line(line):
             "allgather_GBps_per_rank": rf.get("allgather_GBps_per_rank")}
 
 
-def merge_assemblies(cabi_line, cabi_err, torch_line, torch_err):
-    """-> (the line to print, exit code).  Primary = the product's own entry; a failed / timed-out / parity-failing
-    primary is reported and the torch.distributed numbers take its place instead of the run being lost."""
-    cabi_ok = cabi_line is not None and not cabi_err and not cabi_line.get("parity_failed")
-    torch_ok = torch_line is not None and not torch_line.get("parity_failed")
+def merge_assemblies(cabi_line, cabi_err, torch_line, torch_err, torch_rc=0):
+    """-> (the line to print, exit code).  Primary = the product's own entry (gkmhip_gram_allgather); the
+    torch.distributed ranks are the cross-check and, when the primary CRASHES or is killed at its timeout, the fallback
+    (exit code 0: the run is not lost).  A PARITY failure of either assembly is never silent: the other assembly's
+    numbers are kept, but the line says `parity_failed` and the exit code is 3.  A torch launch that ended non-zero
+    (torch_rc) is an error of its own: its line, if one was captured, is reported but never returns 0."""
+    cabi_parity_failed = bool(cabi_line and cabi_line.get("parity_failed"))
+    torch_parity_failed = bool(torch_line and torch_line.get("parity_failed"))
+    torch_failed = bool(torch_rc) and not torch_parity_failed
+    cabi_ok = cabi_line is not None and not cabi_err and not cabi_parity_failed
     if cabi_ok:
         out = cabi_line
         out["assembly"] = "cabi: gkmhip_gram_allgather (one process, one host thread per device)"
-        out.setdefault("also", {})["torch_dist"] = brief_line(torch_line) if torch_line else {"error": torch_err or "no line"}
-        return out, 0
+        also = brief_line(torch_line) if torch_line else {"error": torch_err or "no line"}
+        if torch_line and torch_rc:
+            also["ranks_exit_code"] = torch_rc
+        out.setdefault("also", {})["torch_dist"] = also
+        code = 0
+        if torch_parity_failed:
+            out["parity_failed"] = True
+            out["parity_failed_in"] = "torch.distributed cross-check"
+            code = 3
+        elif torch_line is not None and torch_failed:
+            out["torch_dist_error"] = torch_err or "the torch.distributed ranks ended with exit code %d" % torch_rc
+            code = 1
+        return out, code
     if torch_line is not None:
         out = torch_line
         out["assembly"] = "torch: one process per GPU, torch.distributed all_gather_into_tensor (FALLBACK)"
         out["cabi_error"] = cabi_err or "parity check failed on the gkmhip_gram_allgather matrix"
         if cabi_line:
             out.setdefault("also", {})["cabi"] = brief_line(cabi_line)
-        return out, (0 if torch_ok else 3)
+        if cabi_parity_failed:
+            out["parity_failed"] = True
+            out["parity_failed_in"] = "gkmhip_gram_allgather" + (" and torch.distributed" if torch_parity_failed else "")
+            return out, 3
+        if torch_parity_failed:
+            return out, 3
+        if torch_failed:
+            out["ranks_failed"] = True
+            out["torch_dist_error"] = torch_err or "the torch.distributed ranks ended with exit code %d" % torch_rc
+            return out, 1
+        return out, 0
     sys.stderr.write("bench.py: both assemblies failed: cabi: %s; torch: %s\n" % (cabi_err, torch_err))
     return None, 1
 
@@ -620,40 +673,64 @@ def run_auto(args, argv):
         captured = []
         rc = launch_ranks(targs, torch_argv, capture=captured)
         torch_line = _last_json_line(captured[0]) if captured else None
-        torch_err = None if torch_line else "the torch.distributed ranks failed (exit code %d)" % rc
-        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, torch_err)
+        torch_err = "the torch.distributed ranks failed (exit code %d)" % rc if rc else None
+        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, torch_err, torch_rc=rc)
         if out is not None:
             print(json.dumps(out), flush=True)
         return code
     # under torch.distributed.run: rank 0 runs the child first; the other ranks wait for its verdict in a file
     # (one node, by contract) before anybody imports torch or touches a GPU
     rank = int(os.environ.get("RANK", "0"))
-    sync = os.path.join(tempfile.gettempdir(), "gkm_bench_cabi_%d_%s.json" % (os.getppid(), os.environ.get("MASTER_PORT", "0")))
+    # The verdict file is keyed by this run (launcher pid, port, elastic run id), and a waiting rank only accepts a file
+    # written AFTER it started waiting: a stale file of a crashed earlier run would let ranks != 0 touch their GPUs
+    # while rank 0's child is still measuring on all of them.
+    run_id = "".join(ch for ch in os.environ.get("TORCHELASTIC_RUN_ID", "none") if ch.isalnum())[:32]
+    sync = os.path.join(tempfile.gettempdir(), "gkm_bench_cabi_%d_%s_%s.json"
+                        % (os.getppid(), os.environ.get("MASTER_PORT", "0"), run_id))
     wait_s = float(os.environ.get("GKM_BENCH_CABI_TIMEOUT", "300")) + 60.0
     cabi_line = cabi_err = None
+    t_start = time.time()
     if rank == 0:
         try:
-            if os.path.exists(sync):
-                os.unlink(sync)
+            for stale in [sync] + glob.glob(sync + ".timeout.*"):
+                if os.path.exists(stale):
+                    os.unlink(stale)
             cabi_line, cabi_err = run_cabi_child(args, argv)
         finally:
             with open(sync + ".tmp", "w") as f:
-                json.dump({"line": cabi_line, "error": cabi_err}, f)
+                json.dump({"line": cabi_line, "error": cabi_err, "written_at": time.time()}, f)
             os.replace(sync + ".tmp", sync)
     else:
+        def fresh():
+            try:
+                return os.path.getmtime(sync) >= t_start - 1.0
+            except OSError:
+                return False
         t_end = time.time() + wait_s
-        while not os.path.exists(sync) and time.time() < t_end:
+        while not fresh() and time.time() < t_end:
             time.sleep(0.2)
+        if not fresh():   # reported in rank 0's line: this rank went ahead without the verdict
+            sys.stderr.write("bench.py: rank %d waited %.0f s for rank 0's C-ABI measurement and goes ahead without it\n"
+                             % (rank, wait_s))
+            try:
+                open(sync + ".timeout.%d" % rank, "w").close()
+            except OSError:
+                pass
     holder = []
     rc = run_rank(targs, emit=holder.append)
     if rank == 0:
-        try:
-            os.unlink(sync)
-        except OSError:
-            pass
+        timed_out = sorted(int(x.rsplit(".", 1)[1]) for x in glob.glob(sync + ".timeout.*"))
+        for x in [sync] + glob.glob(sync + ".timeout.*"):
+            try:
+                os.unlink(x)
+            except OSError:
+                pass
         torch_line = holder[0] if holder else None
-        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, None if torch_line else "rank 0 produced no line")
+        out, code = merge_assemblies(cabi_line, cabi_err, torch_line, None if torch_line else "rank 0 produced no line",
+                                     torch_rc=rc if rc != 3 else 0)
         if out is not None:
+            if timed_out:
+                out["cabi_wait_timed_out_on_ranks"] = timed_out
             print(json.dumps(out), flush=True)
         return code
     return rc
@@ -843,11 +920,30 @@ def run_rank(args, emit=None):
         step()
     barrier()
     allocs0 = device.load().gkmhip_allgather_alloc_count() if cabi else 0
+    # N = 1: the Gram kernel's HIP events are kept per launch INSIDE the timed loop (gkmhip_kernel_timeline: no host
+    # wait between the steps) and read after it, and every step is bracketed by events on the launch stream: the
+    # line's kernel_ms and small_kernels_ms are parts of the very steps that ms_per_step times
+    timeline = not dist_on and not cabi
+    step_ev = []
+    if timeline:
+        ctx.kernel_timeline(True)
+        step_ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if timeline:
+            step_ev[i][0].record()
         step()
+        if timeline:
+            step_ev[i][1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_kernel_ms = timed_span_ms = None
+    if timeline:
+        ksum, klaunches = ctx.kernel_timeline_ms()
+        ctx.kernel_timeline(False)
+        if ksum >= 0 and klaunches == args.steps:
+            timed_kernel_ms = ksum / args.steps
+            timed_span_ms = sum(a.elapsed_time(b) for a, b in step_ev) / args.steps
     allocs_timed = (device.load().gkmhip_allgather_alloc_count() - allocs0) if cabi else 0
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -882,6 +978,9 @@ def run_rank(args, emit=None):
             durs.append(ctx.last_kernel_ms())
             comparisons = ctx.last_comparisons()
         del buf
+    elif timed_kernel_ms is not None:
+        durs.append(timed_kernel_ms)
+        comparisons = ctx.last_comparisons()    # 2 n_a n_j summed over the (a, j<=a) pairs: one launch per step
     else:
         for _ in range(max(3, min(args.steps, 5))):
             ms, comparisons = 0.0, 0.0
@@ -995,7 +1094,14 @@ def run_rank(args, emit=None):
             "frac_of_measured_peak": (executed / (peak_meas * n_gpus)) if executed and peak_meas else None,
             "traffic": traffic, "pmc_source": pmc_src,
             "hbm_achieved_GBps": (traffic / kern_s / 1e9) if traffic else None,
-            "kernel": kname, "kernel_ms": kern_ms, "comparisons_per_launch": comparisons,
+            "kernel": kname, "kernel_ms": kern_ms,
+            # N = 1: kernel_ms is the mean over the TIMED steps' own launches; small_kernels_ms is the rest of a step's
+            # span on the launch stream (row tables, untile, self norms, normalise, the gaps between them)
+            "kernel_ms_source": ("HIP events of the timed steps' launches (gkmhip_kernel_timeline)" if timed_kernel_ms is not None
+                                 else "extra launches after the timed region, one device sync each"),
+            "small_kernels_ms": (timed_span_ms - timed_kernel_ms) if timed_kernel_ms is not None else None,
+            "step_span_ms": timed_span_ms,
+            "comparisons_per_launch": comparisons,
             "comparisons_per_s": comparisons / kern_s,
             "executed_insts_per_comparison": ipc,
             # the op model of SURVEY.md §8(d) (6 int32 ops per l-mer comparison): what a comparison-by-comparison

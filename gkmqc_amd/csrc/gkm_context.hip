@@ -176,6 +176,10 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &pr : ctx->tl_pairs) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
     delete ctx;
 }
 
@@ -379,12 +383,60 @@ extern "C" int gkmhip_sync(void *stream)
     return 0;
 }
 
+int gkm_launch_events(gkmhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1)
+{
+    if (ctx->tl_on) {
+        if (ctx->tl_used == ctx->tl_pairs.size()) {
+            hipEvent_t a = nullptr, b = nullptr;
+            HIPCHK(hipEventCreate(&a));
+            if (hipEventCreate(&b) != hipSuccess) {
+                (void)hipEventDestroy(a);
+                return set_err_msg("hipEventCreate failed", 4);
+            }
+            ctx->tl_pairs.emplace_back(a, b);
+        }
+        *e0 = ctx->tl_pairs[ctx->tl_used].first;
+        *e1 = ctx->tl_pairs[ctx->tl_used].second;
+        ctx->tl_used++;
+    } else {
+        *e0 = ctx->ev0;
+        *e1 = ctx->ev1;
+    }
+    ctx->last_e0 = *e0;
+    ctx->last_e1 = *e1;
+    return 0;
+}
+
+extern "C" int gkmhip_kernel_timeline(gkmhip_ctx *ctx, int on)
+{
+    if (!ctx) return set_err_msg("gkmhip_kernel_timeline: bad arguments", 2);
+    ctx->tl_on = on != 0;
+    ctx->tl_used = 0;
+    return 0;
+}
+
+extern "C" double gkmhip_kernel_timeline_ms(gkmhip_ctx *ctx, int *launches)
+{
+    if (launches) *launches = 0;
+    if (!ctx) return -1.0;
+    double sum = 0.0;
+    for (size_t i = 0; i < ctx->tl_used; i++) {
+        float ms = 0.f;
+        if (hipEventSynchronize(ctx->tl_pairs[i].second) != hipSuccess ||
+            hipEventElapsedTime(&ms, ctx->tl_pairs[i].first, ctx->tl_pairs[i].second) != hipSuccess)
+            return -1.0;
+        sum += (double)ms;
+    }
+    if (launches) *launches = (int)ctx->tl_used;
+    return sum;
+}
+
 extern "C" double gkmhip_last_kernel_ms(gkmhip_ctx *ctx)
 {
-    if (!ctx || !ctx->ev_valid) return -1.0;
-    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    if (!ctx || !ctx->ev_valid || !ctx->last_e1) return -1.0;
+    if (hipEventSynchronize(ctx->last_e1) != hipSuccess) return -1.0;
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, ctx->last_e0, ctx->last_e1) != hipSuccess) return -1.0;
     return (double)ms;
 }
 extern "C" double gkmhip_last_comparisons(gkmhip_ctx *ctx) { return ctx ? ctx->last_comparisons : 0.0; }

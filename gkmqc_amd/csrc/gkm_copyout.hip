@@ -53,13 +53,14 @@ __global__ void k_spin(long long ticks, unsigned *sink)
 /* what the drop-in call's copy-out pipeline measured last time (gram_part_to_host_rows cuts its row blocks by it) */
 static struct {
     std::mutex m;
-    double scatter_Bps_per_thread = 0, copy_Bps = 0, cmp_per_s = 0;
+    double scatter_Bps_per_thread = 0, cmp_per_s = 0;
 } g_ship;
 
 struct PipeStreams {
     hipStream_t compute = nullptr, copy = nullptr;
     int probes = 0;
     bool copy_beside = false; /* proven to run beside `compute` */
+    int users = 0;            /* calls that hold the pair right now (gkm_release_pipe_streams leaves those alone) */
 };
 static std::mutex g_pipe_mutex;
 static PipeStreams g_pipe[64];
@@ -104,24 +105,42 @@ extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *
     return got;
 }
 
+/* The device's pair of streams, created and probed at the first call; the caller holds it until pipe_streams_done()
+ * (a concurrent gkmhip_release_host_cache() must not destroy streams a copy-out is using). */
 static int pipe_streams(int device, PipeStreams **out)
 {
     if (device < 0 || device >= 64) return set_err_msg("device ordinal out of range", 2);
     std::lock_guard<std::mutex> lock(g_pipe_mutex);
     PipeStreams &P = g_pipe[device];
     *out = &P;
-    if (P.compute) return 0;
+    if (P.compute && P.copy) {
+        P.users++;
+        return 0;
+    }
+    if (P.compute) (void)hipStreamDestroy(P.compute); /* (a half-built entry of an earlier, failed call) */
+    P = PipeStreams();
     HIPCHK(hipStreamCreateWithFlags(&P.compute, hipStreamNonBlocking));
     void *busy[1] = {P.compute};
     int beside = 0;
     P.copy = (hipStream_t)gkmhip_create_stream_beside(busy, 1, &beside);
     P.copy_beside = beside != 0;
     P.probes = 1;
-    if (!P.copy) return set_err_msg("cannot create the copy-out streams", 4);
+    if (!P.copy) { /* nothing half-built stays behind: the next call starts over */
+        (void)hipStreamDestroy(P.compute);
+        P = PipeStreams();
+        return set_err_msg("cannot create the copy-out streams", 4);
+    }
     if (getenv("GKM_TRACE"))
         fprintf(stderr, "gkmhip: copy-out streams of device %d: the copy stream %s the compute stream\n", device,
                 P.copy_beside ? "runs beside" : "SHARES A QUEUE WITH");
+    P.users++;
     return 0;
+}
+
+static void pipe_streams_done(PipeStreams *P)
+{
+    std::lock_guard<std::mutex> lock(g_pipe_mutex);
+    if (P->users > 0) P->users--;
 }
 
 void gkm_release_pipe_streams()
@@ -131,7 +150,7 @@ void gkm_release_pipe_streams()
     (void)hipGetDevice(&caller);
     for (int d = 0; d < 64; d++) {
         PipeStreams &P = g_pipe[d];
-        if (!P.compute) continue;
+        if (!P.compute || P.users > 0) continue; /* (in use by a copy-out right now: left for the next release) */
         (void)hipSetDevice(d);
         for (hipStream_t x : {P.compute, P.copy})
             if (x) (void)hipStreamDestroy(x);
@@ -227,7 +246,7 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
         const double bytes = total_area * 8.0;
         /* (before anything has been measured: one thread moves ~15-20 GB/s into pageable memory, sixteen ~60) */
         const double per_thread = g_ship.scatter_Bps_per_thread > 0 ? g_ship.scatter_Bps_per_thread : 15.0e9 / sqrt((double)nthreads);
-        const double ship_Bps = std::min(per_thread * nthreads, g_ship.copy_Bps > 0 ? g_ship.copy_Bps : 50.0e9);
+        const double ship_Bps = std::min(per_thread * nthreads, 50.0e9); /* (the device-to-host copy itself: ~50 GB/s) */
         const double cmp_rate = g_ship.cmp_per_s > 0 ? g_ship.cmp_per_s : 1.0e14;
         const double cmp = ctx->h_cum_n.empty() ? 0.0 : ctx->h_cum_n[(size_t)n] * ctx->h_cum_n[(size_t)n]; /* ~2 n_a n_j over j <= a */
         ship_ratio = cmp > 0 ? (bytes / ship_Bps) / (cmp / cmp_rate) : 0.5;
@@ -283,6 +302,10 @@ static int gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
      * kernels off sc in round 4: see gram_launch.) */
     PipeStreams *ps = nullptr;
     if (pipe_streams(ctx->device, &ps)) return 4;
+    struct Holder { /* hands the pair back on every path out of this function */
+        PipeStreams *p;
+        ~Holder() { pipe_streams_done(p); }
+    } hold{ps};
     const double streams_ms = now() - t0; /* (first call: the streams are created and probed) */
     const hipStream_t sc = ps->compute, sd = ps->copy;
     std::vector<hipEvent_t> done(B, nullptr);

@@ -105,6 +105,7 @@ __global__ __launch_bounds__(64) void k_gram_direct(const DirectArgs A)
 {
     constexpr int R = 8;
     __shared__ uint32_t acc[GKM_MAXD1][64];
+    static_assert(GKM_MAXD1 >= 12 + 1, "acc has a row for every possible mismatch count m <= L <= 12 (no test for m <= d below)");
     const int lane = threadIdx.x;
     const int tile = blockIdx.y;
     const int ridx = tile * 64 + lane;
@@ -261,7 +262,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
          * kernel depend on its occupancy? */
         const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->wd_len + 3) / 4) * sizeof(uint32_t) + lds_pad;
+        /* dynamic LDS of a wave: the column's two packed strands + its weight bytes by position with L - 1 zeros either side */
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->maxlen + L - 1 + 3) / 4) * sizeof(uint32_t) + lds_pad;
         bool bperm = false;
         if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
             hipFuncAttributes fa, fb;
@@ -410,8 +412,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
         A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
-        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd32 = (const uint32_t *)ctx->wd.p;
-        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4;
+        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
+        A.rpw = rpw; A.pkw = ctx->pkw;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
@@ -428,10 +430,12 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
          * the drain at the end of every launch costs -- nothing for one big launch, but the boundary call
          * issues 13 launches and the multi-GPU path one per chunk. */
-        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipEvent_t e0, e1;
+        if (gkm_launch_events(ctx, &e0, &e1)) return 4;
+        HIPCHK(hipEventRecord(e0, stream));
         hipLaunchKernelGGL(bs, dim3((unsigned)n_items), dim3(64), dyn_lds, stream, A);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        HIPCHK(hipEventRecord(e1, stream));
         if (out.G) {
             int span = 0;
             for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
@@ -443,6 +447,14 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                 hipLaunchKernelGGL(k_untile<64>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
                                    A.tile_nrows, A.tile_row, A.tile_out, A.out);
             HIPCHK(hipGetLastError());
+        }
+        if (getenv("GKM_TRACE")) { /* the occupancy the runtime grants this instantiation with this much dynamic LDS */
+            int per_cu = 0;
+            hipFuncAttributes fa;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bs, 64, dyn_lds) == hipSuccess &&
+                hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess)
+                fprintf(stderr, "gkmhip: hot kernel: %d VGPRs, %zu + %zu bytes of LDS per wave, %d one-wave workgroups per CU\n",
+                        fa.numRegs, (size_t)fa.sharedSizeBytes, dyn_lds, per_cu);
         }
         ctx->last_kernel = bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
     } else {
@@ -475,14 +487,19 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
          * sequences: 2 000 workgroups of 16 columns left three quarters of the SIMDs idle, 156 ms; now 2 columns) */
         A.cj = (int)std::min(16.0, std::max(1.0, floor(items / 16384.0)));
         const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
-        HIPCHK(hipEventRecord(ctx->ev0, stream));
+        hipEvent_t e0, e1;
+        if (gkm_launch_events(ctx, &e0, &e1)) return 4;
+        HIPCHK(hipEventRecord(e0, stream));
         hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(ctx->ev1, stream));
+        HIPCHK(hipEventRecord(e1, stream));
         ctx->last_kernel = "k_gram_direct";
     }
     ctx->ev_valid = true;
     ctx->last_comparisons = comparisons;
+    if (getenv("GKM_TRACE")) /* which kernel served this launch, and the rule's input: a regression on data far from iid shows here */
+        fprintf(stderr, "gkmhip: %d rows -> %s (preference %d; iid hit share of (L=%d, d=%d) %.4f, bit-sliced up to %.3f)\n", nrows,
+                ctx->last_kernel, ctx->kernel_pref, L, d, iid_hit_share(L, d), (double)GKM_BITSLICE_MAX_HIT_SHARE);
     return 0;
 }
 

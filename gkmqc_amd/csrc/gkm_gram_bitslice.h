@@ -14,8 +14,8 @@ struct BsArgs {
     const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
     const uint32_t *rowpk;      /* [tile*64 + lane][rpw] the lanes' positions, 2-bit packed (k_build_rowplanes) */
     const uint32_t *colpk;      /* [seq][pkw][strand] 2-bit packed strands, the two strands interleaved        */
-    const uint32_t *wd32;       /* distance-indexed positional weights (bytes), wd_words dwords               */
-    int rpw, pkw, wd_words;
+    const uint8_t *wd8;         /* distance-indexed positional weights wd[|n/2 - p|], WD_LDS bytes (ones if unweighted) */
+    int rpw, pkw;
     const uint32_t *sb;
     int xw;
     const int *len;

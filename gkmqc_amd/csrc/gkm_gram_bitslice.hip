@@ -38,6 +38,14 @@ __device__ __forceinline__ uint32_t twice(uint32_t x)
     return r;
 }
 
+/* |a - b| in one instruction (hipcc expands __usad(a, b, 0) into v_min / v_max / v_sub) */
+__device__ __forceinline__ uint32_t absdiff(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_sad_u32 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 /* popcount(x) + acc in one instruction (hipcc sums separate popcounts with extra adds) */
 __device__ __forceinline__ uint32_t popc_add(uint32_t x, uint32_t acc)
 {
@@ -92,33 +100,45 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      * them from revision a4bed73, profiles/r2_ablation_timings.txt and r2_pmc_ablation_builds*.txt hold what they
      * measured.) */
     using namespace gkmbs;
-    /* LDS per wave: 3 KB hit list + 0-1.3 KB piece table + 1-2.5 KB accumulators + (dynamic) the column's two
-     * 2-bit packed strands and the distance-indexed weight table, 0.4 KB at 300 bp, 0.7 KB at 600 bp.  What the
-     * hit resolution reads per hit: two words of the column strand and two weight bytes from LDS, two words
-     * of the row lane's packed positions from global memory (8 KB per tile -- 128 bytes per lane, of which 84 are
-     * used -- L1 resident: the waves of a CU work on the same tile). */
-    extern __shared__ uint32_t s_dyn[]; /* [wd_words] weight bytes, then [2 * pkw] column strands (forward, reverse complement) */
-    /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
-     * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin at
-     * k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
-     * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
-     * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
-    __shared__ uint32_t s_list[(BS_GRP + 1) * BS_CAP];
-    /* (array BS_GRP of s_list: first word of the group, delta, strand, row lane) */
+    /* LDS per wave.  STATIC, one array carved by hand so that the mismatch profiles come FIRST (see `resolve`: a hit adds
+     * at accl + m * NSLOT + slot without testing m <= D; the windows with a larger m are the ones that wrap around the
+     * end of the column strand, they carry the weight 0, and wherever m <= L lands it is inside this array):
+     *   accl   [(D + 1) * NSLOT]     mismatch profiles [m][row slot]                              1-2.5 KB
+     *   s_list [(BS_GRP + 1) * CAP]  the hit list                                                 3 KB
+     *   lmask  [64]                  PACKED: piece-start bit rows of every lane                   0.25 KB
+     *   lpiece [64 * NP | 128 | 0]   piece entries (none in the BPERM variant)                    0-1 KB
+     * DYNAMIC: the column's two 2-bit packed strands, interleaved word by word (2 * pkw words: 0.2 KB at 300 bp, 0.3 KB
+     * at 600 bp), then the column's positional weights by l-mer position with L - 1 zero bytes either side (T + L - 1
+     * bytes).  What the hit resolution reads per hit: two words of the column strand and one weight byte from LDS; two
+     * words of the row lane's packed positions (8 KB per tile -- 128 bytes per lane, of which 84 are used -- L1
+     * resident: the waves of a CU work on the same tile) and the row l-mer's weight byte (the 1-KB distance table)
+     * from global memory. */
+    extern __shared__ uint32_t s_dyn[];
     /* PACKED: lanes may hold several pieces (gkm_pack.h).  When no lane of the call holds more than one
      * piece (e.g. every fixed-length data set) the leaner variant runs: one (slot, centre) pair per lane.
      * The several-pieces variant exists for 64 and for 128 row slots per tile: the profiles of 128 slots
      * (2.5 KB at d = 4) cost a wave per SIMD, so the host packs at most 64 rows into a tile unless
-     * that would leave lanes empty (many rows shorter than half a lane).  LDS per wave, d = 4, 600 bp:
-     * 3 KB ring + 0.25 KB piece starts + 1 KB piece table + 1.25 KB profiles + 0.6 KB strands and weights
-     * = 6.1 KB -> 6 waves per SIMD (8.4 KB -> 4.75 with 128 slots and two-word piece entries). */
+     * that would leave lanes empty (many rows shorter than half a lane). */
     constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
     constexpr int NSLOT = PK == 2 ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
-    __shared__ uint32_t lmask[PACKED ? 64 : 1];  /* piece-start bit rows of every lane         */
+    constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = (BS_GRP + 1) * BS_CAP, LMASK_WORDS = PACKED ? 64 : 0;
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
-    __shared__ uint32_t lpiece[PACKED ? 64 * NP : BPERM ? 1 : 128];
-    __shared__ uint32_t accl[(D + 1) * NSLOT];   /* mismatch profiles [m][row slot]            */
+    constexpr int LPIECE_WORDS = PACKED ? 64 * NP : BPERM ? 0 : 128;
+    constexpr int STATIC_WORDS = ACC_WORDS + LIST_WORDS + LMASK_WORDS + LPIECE_WORDS;
+    __shared__ uint32_t s_mem[STATIC_WORDS];
+    uint32_t *const accl = s_mem; /* mismatch profiles [m][row slot] */
+    /* The hit list.  A record is the BS_GRP hit words of one lane for BS_GRP consecutive words of a
+     * shift plus their origin; word k of record i sits at s_list[k * BS_CAP + i], the origin (first word of the
+     * group, shift, row lane) at k = BS_GRP (arrays a multiple of 64 dwords apart: the stores of a push merge into
+     * ds_write2st64_b32).  Compacting once per group instead of once per word takes 3 VALU
+     * instructions per word out of the hot loop (config 2: 111.0 -> 96.2 ms). */
+    uint32_t *const s_list = s_mem + ACC_WORDS;
+    uint32_t *const lmask = s_mem + ACC_WORDS + LIST_WORDS;
+    uint32_t *const lpiece = lmask + LMASK_WORDS;
+    static_assert((ACC_WORDS * 4) % 256 == 0, "the list's arrays stay 64-dword aligned (ds_write2st64_b32)");
+    /* an add at accl[m <= L][slot] stays inside the static LDS (everywhere but 128 slots with d <= 1) */
+    constexpr bool M_FITS = (L + 1) * NSLOT <= STATIC_WORDS;
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a STACK (round 3; a ring before): a trip is due as soon as it holds BS_TRIP records and it is checked
      * after every group (at most 64 new records); a trip takes the BS_TRIP records on TOP and puts at most as many back:
@@ -186,15 +206,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         my_both = A.lane_piece[(size_t)(tile * 64 + lane) * 2] | (A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1] << 16);
     const uint32_t lane_tag = (uint32_t)lane << META_LANE_SHIFT, lane4 = (uint32_t)lane << 2;
     const int pkw = A.pkw;
-    /* dynamic LDS: the column's two packed strands first, interleaved word by word (their address is then a constant
-     * of the kernel and folds into the offset field of the reads), the weight table behind them (its offset rides in
-     * the third operand of the v_sad_u32 that forms the index) */
+    /* dynamic LDS: the column's two packed strands first, interleaved word by word, the column's weight bytes behind them */
     uint32_t *const s_col = s_dyn;
-    /* byte offset of the weight table, kept in a VGPR: the column-side index |q - centre| + wbase would otherwise name
-     * two SGPRs in one v_sad_u32 (one is the limit) and cost a v_mov per hit */
-    uint32_t wbase;
-    asm volatile("v_mov_b32 %0, %1" : "=v"(wbase) : "s"((uint32_t)pkw * 8u));
-    for (int x = lane; x < A.wd_words; x += 64) s_dyn[2 * pkw + x] = A.wd32[x];
+    uint8_t *const s_wcol = (uint8_t *)(s_dyn + 2 * pkw);
     /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
      * base instead of a 64-bit address computed per lane); 128 bytes per lane, so that the lane field of a
      * record's origin word IS the lane's byte offset */
@@ -205,11 +219,25 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
         for (int x = lane; x < 2 * pkw; x += 64) s_col[x] = A.colpk[(size_t)j * 2 * pkw + x];
-        /* weight of a column l-mer q: forward strand wd[|nB/2 - q|]; reverse strand wt_rc[q] = wt[nB-1-q]
-         * (libgkm.c:924) = wd[|nB/2 - (nB-1-q)|] = wd[|q + [nB even] - nB/2|]; the [nB even] of the reverse strand
-         * travels in bit 5 of the record's origin word (pack_meta) */
+        /* The column's positional weights BY POSITION, L - 1 zero bytes either side: s_wcol[L - 1 + p] = wt[p] =
+         * wd[|nB/2 - p|] for the l-mers p < nB (libgkm.c:912-925).  A forward-strand window q reads s_wcol[L - 1 + q]; the
+         * reverse strand's weights are the forward ones mirrored, wt_rc[q] = wt[nB-1-q] (libgkm.c:924), so it reads
+         * s_wcol[L - 1 + nB - 1 - q].  The windows that wrap around the end of the strand (q = nB .. T - 1: not l-mers,
+         * gkm_bitslice.h window_hits) land in the zero bytes behind / before the table: they add 0 to some profile
+         * word and need no test.  (Round 5; before, a distance-indexed table served both sides and a trip compared
+         * q with nB: the table by position is what makes the zeros possible -- |nB/2 - q| of q = nB equals that of
+         * q = 0 when nB is even.) */
         const uint32_t ccen = (uint32_t)(nB / 2);
-        const int ceven = (nB & 1) ? 0 : 1;
+        for (int x = lane; x < T + L - 1; x += 64) {
+            const int p = x - (L - 1), dd = (int)ccen - p;
+            s_wcol[x] = (p >= 0 && p < nB) ? A.wd8[dd < 0 ? -dd : dd] : (uint8_t)0;
+        }
+        /* strand-uniform scalars of the hit path (set at the top of each strand's sweep; the list is emptied between
+         * the strands, so a trip only ever holds records of ONE strand and the strand costs it no instruction):
+         *   s_strand4   byte offset of the strand's words in the interleaved column image (0 / 4)
+         *   s_wsign     0 / ~0: the weight index is (q ^ s_wsign) + s_wbase = L-1 + q  or  L-1 + nB-1 - q, plus the
+         *               table's byte offset in the dynamic LDS */
+        uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u;
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < (two_copies ? NSLOT : nrows); rs += 64) accl[m * NSLOT + rs] = 0u;
@@ -224,7 +252,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * anything with an SGPR operand take twice as long (tools/valu_ops.hip).  Hence the layout of the origin
          * word (gkm_bitslice.h pack_meta: fields that are masked in place or shifted out of the top), 128 bytes per
          * lane of packed positions, the column's strands interleaved word by word, (a & const) | b as one
-         * v_bitop3_b32, the weight table's LDS offset as the third operand of the v_sad_u32 that forms the index.
+         * v_bitop3_b32, the strand as wave-uniform scalars (the list is emptied between the strands).
          * Same arithmetic as resolve_hit_packed (gkm_bitslice.h), which the CPU tests run against the oracle. */
         auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
             const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
@@ -248,21 +276,21 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             uint32_t q;
             if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
             else q = mod_small(x, (uint32_t)T, rcpT);
-            /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits) */
-            if ((int)q < nB) {
-                /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
-                const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
-                const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, (ms >> 2) & 4u));
-                const uint8_t *wdb = (const uint8_t *)s_dyn;
-                const uint32_t wa = wdb[__usad(c0b, i0 | 2048u, wbase)];
-                const uint32_t wb = wdb[__usad(q + ((ms >> 5) & 1u), ccen, wbase)];
-                /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
-                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
-                const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
-                const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
-                if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 */
-                    atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
-            }
+            /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
+            const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+            const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, s_strand4));
+            const uint32_t wa = A.wd8[absdiff(c0b, i0 | 2048u)];
+            const uint32_t wb = ((const uint8_t *)s_dyn)[(q ^ s_wsign) + s_wbase];
+            /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
+            const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
+            const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
+            const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
+            /* No test for m <= D and none for a wrapped column window: a window that is an l-mer on both sides has the m
+             * the counting loop found (<= D); one that wraps around the end of the strand (packed strands: zeros behind
+             * the end, so any m <= L) has wb = 0 and adds nothing, wherever m * NSLOT + slot lies in the static LDS
+             * (M_FITS).  LDS atomic: ds_add_u32. */
+            if (M_FITS || m <= (uint32_t)D)
+                atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
         };
 
         /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
@@ -297,7 +325,32 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             for (int g = 1; g < BS_GRP; g++) first = min(first, ffbl_or_ones(h[g]) | (uint32_t)(g << 5));
 #pragma unroll
             for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
-            const uint32_t sel = first >> 5, bit = first & 31u;
+            uint32_t sel = first >> 5;
+            const uint32_t bit = first & 31u;
+#if defined(GKM_PROBE_VALU_F) || defined(GKM_PROBE_VALU_H) || defined(GKM_PROBE_LDS) || defined(GKM_PROBE_LAT)
+            /* SENSITIVITY PROBES (experiments only, results unchanged): what one more full-rate / half-rate VALU
+             * instruction, one more LDS operation, one more dependent LDS round trip per trip costs */
+            {
+                uint32_t dummy = total;
+#ifdef GKM_PROBE_VALU_F
+#pragma unroll
+                for (int z = 0; z < GKM_PROBE_VALU_F; z++) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(dummy) : "v"(first));
+#endif
+#ifdef GKM_PROBE_VALU_H
+#pragma unroll
+                for (int z = 0; z < GKM_PROBE_VALU_H; z++) asm volatile("v_bcnt_u32_b32 %0, %0, %1" : "+v"(dummy) : "v"(first));
+#endif
+#ifdef GKM_PROBE_LDS
+#pragma unroll
+                for (int z = 0; z < GKM_PROBE_LDS; z++) asm volatile("ds_add_u32 %0, %1" : : "v"(lane4), "v"(0u) : "memory");
+#endif
+#ifdef GKM_PROBE_LAT
+#pragma unroll
+                for (int z = 0; z < GKM_PROBE_LAT; z++) sel = (uint32_t)__builtin_amdgcn_ds_bpermute((int)lane4, (int)sel);
+#endif
+                asm volatile("" : : "v"(dummy));
+            }
+#endif
             const uint32_t ms = meta + sel; /* the word index w0 + sel <= W - 1 stays inside its 4 bits */
             uint32_t pslot4 = 0u, pc0b = 0u;
             if (BPERM) { /* every lane takes part (ds_bpermute_b32 reads 0 from lanes that EXEC masks out) */
@@ -345,6 +398,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         };
 
         for (int strand = 0; strand < 2; strand++) {
+            s_strand4 = (uint32_t)strand * 4u;
+            s_wsign = strand ? ~0u : 0u;
+            s_wbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u); /* ~q = -q - 1 */
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
             const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
@@ -366,7 +422,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                     if (d0 + u < T) {
                         uint32_t hit[W];
                         window_hits<W, L, D>(Ahi, Alo, AV, bh + u, bl + u, (const uint32_t *)nullptr, hit);
-                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, strand, ceven);
+                        const uint32_t vbase = lane_tag | pack_meta(d0 + u, 0, 0);
 #pragma unroll
                         for (int w0 = 0; w0 < W; w0 += BS_GRP) {
                             /* wave-level compaction at the source, once per group of BS_GRP words: the
@@ -392,8 +448,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                     }
                 }
             }
+            trips(true); /* the list is empty before the other strand starts: see s_strand4 */
         }
-        trips(true);
 
         /* epilogue: one lane per row slot of the tile */
 #pragma unroll

@@ -120,11 +120,20 @@ struct gkmhip_ctx {
     } scratch[GKM_SCRATCH_SLOTS];
     int sel = 0;
     DevBuf<double> sq;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr; /* around the Gram kernel of the most recent launch */
     bool ev_valid = false;
+    /* gkmhip_kernel_timeline: while on, every launch records its own pair of events (no host wait in between), so
+     * that a caller can time a loop of launches from outside and read the kernels' share of it afterwards */
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> tl_pairs;
+    size_t tl_used = 0;
+    bool tl_on = false;
+    hipEvent_t last_e0 = nullptr, last_e1 = nullptr;
     double last_comparisons = 0;
     const char *last_kernel = "none";
 };
+
+/* the pair of events the next Gram kernel is bracketed by (gkm_context.hip) */
+int gkm_launch_events(gkmhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);
 
 constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| + 1 for n <= 2047 */
 

@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -198,6 +199,10 @@ struct Call {
     std::atomic<int> failed{0};
     std::atomic<int> stuck{0}; /* a collective was enqueued by some ranks only: do not wait for it */
     HostBarrier *bar = nullptr;
+    /* >= 0: gkmhip_gram_rank_alone -- only this rank runs, ALONE on its device: its own slab goes into its gathered
+     * buffer by a device copy, the peers' slabs are what an earlier gkmhip_gram_allgather of the same shape left there */
+    int alone = -1;
+    double wall_ms = 0; /* (alone) the rank's step on the host clock: first enqueue -> everything complete */
 };
 
 /* what the most recent call measured, per rank (gkmhip_allgather_stats) */
@@ -265,6 +270,8 @@ void rank_thread(Call &C, int g)
     C.bar->wait();
     hipStream_t *sk = R.sk, sc = R.sc;
     RankStats st_out;
+    timespec ts_step0;
+    clock_gettime(CLOCK_MONOTONIC, &ts_step0);
 
     /* ---- phase 1: per chunk, the Gram kernel of this rank's rows, then the all-gather of the slab ---- */
     for (int c = 0; c < chunks; c++) {
@@ -307,9 +314,10 @@ void rank_thread(Call &C, int g)
             if (!C.bar->wait(C.failed.load() != 0)) {
                 /* first every peer's slab, THEN the start event: transfer_ms brackets the copies only, as the RCCL
                  * branch's brackets the collective only (not the wait for the slowest peer's kernel) */
-                for (int r = 0; r < G && !fail; r++) MCHK(hipStreamWaitEvent(sc, g_cache[r].ready[(size_t)c], 0));
+                const int r_lo = C.alone >= 0 ? g : 0, r_hi = C.alone >= 0 ? g + 1 : G;
+                for (int r = r_lo; r < r_hi && !fail; r++) MCHK(hipStreamWaitEvent(sc, g_cache[r].ready[(size_t)c], 0));
                 MCHK(hipEventRecord(R.a0[(size_t)c], sc));
-                for (int r = 0; r < G && !fail; r++) {
+                for (int r = r_lo; r < r_hi && !fail; r++) {
                     MCHK(hipMemcpyPeerAsync(R.gathered + ((size_t)c * (size_t)G + (size_t)r) * slab_elems, dev,
                                             g_cache[r].slab + (size_t)c * slab_elems, C.devs[(size_t)r],
                                             slab_elems * sizeof(double), sc));
@@ -335,6 +343,11 @@ void rank_thread(Call &C, int g)
     if (sc && !C.stuck.load()) {
         hipError_t e = hipStreamSynchronize(sc);
         if (e != hipSuccess && !fail) { fail = true; C.err[(size_t)g] = std::string("hipStreamSynchronize: ") + hipGetErrorString(e); }
+    }
+    {
+        timespec ts_step1;
+        clock_gettime(CLOCK_MONOTONIC, &ts_step1);
+        if (C.alone >= 0) C.wall_ms = (ts_step1.tv_sec - ts_step0.tv_sec) * 1e3 + (ts_step1.tv_nsec - ts_step0.tv_nsec) * 1e-6;
     }
     if (assembled && !fail) {
         float ms = 0.f;
@@ -383,6 +396,57 @@ extern "C" int gkmhip_allgather_stats(double *out, int cap)
         out[6 + 4 * g] = g_stats[g].comparisons;
     }
     return need;
+}
+
+/* ONE rank of a `ranks`-way gkmhip_gram_allgather, alone on its device: what a rank's step costs without the transfer.
+ * No node with several GPUs has been available to any round, and a rehearsal with all ranks on one device makes every
+ * rank's kernel `ranks` times too long; this runs rank `rank`'s own chunks (same layout, streams, scratch slots, packed
+ * slabs, events as rank_thread above -- it IS rank_thread), puts its slab into its gathered buffer with a device copy
+ * and assembles + normalises the whole matrix from that buffer, whose other ranks' slabs must be there from an earlier
+ * gkmhip_gram_allgather call with the same contexts' shape (n, ranks, chunks) -- the call fails if they are not.
+ * out[0..5] = wall ms (host clock, first enqueue -> all streams complete), kernel ms (sum over the chunks' launches,
+ * table uploads / row planes / untile included), copy-in ms, assemble ms, comparisons, chunks. */
+extern "C" int gkmhip_gram_rank_alone(gkmhip_ctx *ctx, int rank, int ranks, int chunks, double *K, int64_t ld, int symmetric,
+                                      double *out6)
+{
+    if (!ctx || !K || ranks < 1 || ranks > 64 || rank < 0 || rank >= ranks) return fail_with("gkmhip_gram_rank_alone: bad arguments", 2);
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    Call C;
+    C.G = ranks;
+    C.n = gkmhip_n_sequences(ctx);
+    if (C.n <= 0 || ld < C.n) return fail_with("gkmhip_gram_rank_alone: no sequences uploaded or leading dimension too small", 2);
+    C.chunks = ranks == 1 ? 1 : (chunks > 0 ? chunks : gkmshard::auto_chunks(C.n, ranks));
+    C.pe = gkmshard::packed_chunk_elems(C.n, ranks, C.chunks);
+    const RankCache &R = g_cache[rank];
+    if (!(R.dev == gkmhip_device_of(ctx) && R.n == C.n && R.G == ranks && R.chunks == C.chunks && R.pe == C.pe))
+        return fail_with("gkmhip_gram_rank_alone: no gathered slabs of this shape (run gkmhip_gram_allgather with the same "
+                         "number of contexts and chunks first)", 2);
+    std::vector<gkmhip_ctx *> ctxs((size_t)ranks, nullptr);
+    std::vector<double *> Ks((size_t)ranks, nullptr);
+    ctxs[(size_t)rank] = ctx;
+    Ks[(size_t)rank] = K;
+    C.ctxs = ctxs.data();
+    C.K = Ks.data();
+    C.ld = ld;
+    C.symmetric = symmetric;
+    C.devs.assign((size_t)ranks, gkmhip_device_of(ctx));
+    C.row_offset = gkmshard::packed_gather_offsets(C.n, ranks, C.chunks);
+    C.err.assign((size_t)ranks, std::string());
+    C.alone = rank;
+    HostBarrier bar(1);
+    C.bar = &bar;
+    if (g_stats.size() != (size_t)ranks) g_stats.assign((size_t)ranks, RankStats());
+    int caller_device = -1;
+    (void)hipGetDevice(&caller_device);
+    rank_thread(C, rank);
+    if (caller_device >= 0) (void)hipSetDevice(caller_device);
+    if (C.failed.load()) return fail_with("gkmhip_gram_rank_alone failed: " + C.err[(size_t)rank], 7);
+    if (out6) {
+        const RankStats &st = g_stats[(size_t)rank];
+        out6[0] = C.wall_ms; out6[1] = st.kernel_ms; out6[2] = st.transfer_ms; out6[3] = st.assemble_ms;
+        out6[4] = st.comparisons; out6[5] = (double)C.chunks;
+    }
+    return 0;
 }
 
 extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, int64_t ld, int symmetric, int chunks)

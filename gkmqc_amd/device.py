@@ -139,6 +139,9 @@ def load():
     L.gkmhip_device_of.argtypes = (vp,)
     L.gkmhip_gram_allgather.restype = i32
     L.gkmhip_gram_allgather.argtypes = (vp, i32, vp, i64, i32, i32)
+    if hasattr(L, "gkmhip_gram_rank_alone"):   # (a GKM_LIB_PATH library built from an older revision lacks it: A/B runs)
+        L.gkmhip_gram_rank_alone.restype = i32
+        L.gkmhip_gram_rank_alone.argtypes = (vp, i32, i32, i32, vp, i64, i32, vp)
     L.gkmhip_last_transport.restype = ctypes.c_char_p
     L.gkmhip_release_comms.restype = None
     if hasattr(L, "gkmhip_allgather_stats"):   # (older builds loaded through GKM_LIB_PATH for A/B timing lack them)
@@ -149,6 +152,10 @@ def load():
     L.gkmhip_assemble_normalize.argtypes = (vp, vp, i64, vp, vp, i64, vp, i32, vp)
     L.gkmhip_last_kernel_ms.restype = dbl
     L.gkmhip_last_kernel_ms.argtypes = (vp,)
+    if hasattr(L, "gkmhip_kernel_timeline"):
+        L.gkmhip_kernel_timeline.argtypes = (vp, ctypes.c_int)
+        L.gkmhip_kernel_timeline_ms.restype = dbl
+        L.gkmhip_kernel_timeline_ms.argtypes = (vp, ctypes.POINTER(ctypes.c_int))
     L.gkmhip_last_comparisons.restype = dbl
     L.gkmhip_last_comparisons.argtypes = (vp,)
     L.gkmhip_last_kernel_name.restype = ctypes.c_char_p
@@ -336,6 +343,15 @@ class GramContext:
 
     def last_kernel_ms(self):
         return self.lib.gkmhip_last_kernel_ms(self.handle)
+
+    def kernel_timeline(self, on):
+        """While on, every launch keeps its own event pair: kernel_timeline_ms() sums the Gram kernels of a loop."""
+        self._chk(self.lib.gkmhip_kernel_timeline(self.handle, 1 if on else 0), "gkmhip_kernel_timeline")
+
+    def kernel_timeline_ms(self):
+        k = ctypes.c_int(0)
+        ms = self.lib.gkmhip_kernel_timeline_ms(self.handle, ctypes.byref(k))
+        return ms, k.value
 
     def last_comparisons(self):
         return self.lib.gkmhip_last_comparisons(self.handle)

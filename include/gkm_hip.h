@@ -153,6 +153,15 @@ int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
  * cross-validation (include/gkm_svm.h) from an N-GPU matrix; the reference's consumer is
  * scripts/gkmsvm.py:104-122. */
 int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, int64_t ld, int symmetric, int chunks);
+/* ONE rank of a `ranks`-way gkmhip_gram_allgather ALONE on its device (measurement: what a rank's step costs without
+ * the transfer, on a box with one GPU): rank `rank`'s chunks exactly as gkmhip_gram_allgather runs them (same layout,
+ * streams, scratch slots, packed slabs), its slab copied into its gathered buffer on the device, then the whole matrix
+ * assembled and normalised into K from that buffer -- whose other ranks' slabs must be there from an earlier
+ * gkmhip_gram_allgather over `ranks` contexts with the same `chunks` (all on this device: the one-GPU rehearsal).
+ * out6 = {wall ms on the host clock, kernels ms (sum over the chunks' launches incl. tables / row planes / untile),
+ * copy-in ms, un-permute + normalise ms, l-mer comparisons, chunks}. */
+int gkmhip_gram_rank_alone(gkmhip_ctx *ctx, int rank, int ranks, int chunks, double *K, int64_t ld, int symmetric,
+                           double *out6);
 /* "rccl", "p2p" or "none": how the most recent gkmhip_gram_allgather moved the slabs */
 const char *gkmhip_last_transport(void);
 /* RCCL communicators AND each rank's buffers (its slab, the gathered slabs, gather index, self norms, streams,
@@ -192,6 +201,11 @@ void gkmhip_release_host_cache(void);
 /* elapsed milliseconds of the device work of the most recent gkmhip_gram_rows call
  * (HIP events recorded on its stream around the dominant kernel); <0 if unavailable */
 double gkmhip_last_kernel_ms(gkmhip_ctx *ctx);
+/* Timing a LOOP of launches from outside: between gkmhip_kernel_timeline(ctx, 1) and gkmhip_kernel_timeline(ctx, 0) every
+ * launch keeps its own pair of events (no host wait in between); gkmhip_kernel_timeline_ms waits for them and returns
+ * the sum of the Gram kernels' durations since the last switch-on (*launches = how many), <0 on failure. */
+int gkmhip_kernel_timeline(gkmhip_ctx *ctx, int on);
+double gkmhip_kernel_timeline_ms(gkmhip_ctx *ctx, int *launches);
 /* number of l-mer comparisons that call evaluated (algorithmic: 2 n_a n_j per pair) */
 double gkmhip_last_comparisons(gkmhip_ctx *ctx);
 const char *gkmhip_last_kernel_name(gkmhip_ctx *ctx);

@@ -168,3 +168,19 @@ def ref_profiles(opt, maxn=4096, wt_stride=2048):
     del P
     P = flat[: n * n * (opt.d + 1)].reshape(n, n, opt.d + 1).copy()
     return dict(P=P, sqnorm=sq[:n].copy(), lens=lens[:n].copy(), wt=wt[:n].copy(), n_pos=npos.value, n=n)
+
+
+def ref_batch_rows(opt, rows, maxn=4096):
+    """Rows `rows` of the problem scored against ALL its sequences by the reference's batch-vs-set entry
+    gkmkernel_kernelfunc_batch (src/libgkm.c:1115-1153): [len(rows), n] normalised kernel values (RBF applied for
+    types 3 / 5; the diagonal entry is G / sqnorm^2 as the reference computes it, not forced to 1.0)."""
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    out = np.zeros((len(rows), maxn), dtype=np.float64)
+    n = ref_probe().refp_batch_rows(opt.kernel_type, opt.L, opt.k, opt.d, int(opt.M), ctypes.c_double(opt.H),
+                                    ctypes.c_double(opt.gamma), opt.posfile, opt.negfile,
+                                    rows.ctypes.data_as(ctypes.c_void_p), len(rows), maxn,
+                                    out.ctypes.data_as(ctypes.c_void_p))
+    if n < 0:
+        raise ValueError("refp_batch_rows failed (%d)" % n)
+    # the probe addresses `out` with the true n as row stride
+    return out.reshape(-1)[: len(rows) * n].reshape(len(rows), n).copy()

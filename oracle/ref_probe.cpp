@@ -75,4 +75,35 @@ int refp_profiles(int kernel_type, int L, int k, int d, int M, double H, double 
     return N;
 }
 
+/* The reference's batch-vs-set scoring entry, gkmkernel_kernelfunc_batch (libgkm.c:1115-1153; exported by its .so,
+ * unused by gkm_main_pywrapper: SURVEY.md section 8 row a14 / f4), driven as a caller would: the problem is read and its
+ * tree built, then row rows[i] is scored against ALL n sequences of the problem (db_array = the problem's own records;
+ * the DFS it runs goes over the problem tree with last_seqid = n, libgkm.c:553-589).  out is [nrows][n]: normalised,
+ * RBF applied for types 3 / 5, the diagonal entry as the reference computes it (G / sqnorm^2, not forced to 1.0).
+ * Returns n, or < 0. */
+int refp_batch_rows(int kernel_type, int L, int k, int d, int M, double H, double gamma,
+                    const char *posfile, const char *negfile, const int *rows, int nrows, int maxn, double *out)
+{
+    gkm_parameter param;
+    svm_problem prob;
+    param.kernel_type = kernel_type; param.L = L; param.k = k; param.d = d;
+    param.M = (u_int8_t)M; param.H = H; param.gamma = gamma; param.nthreads = 1;
+    clog_init_fd(LOGGER_ID, 1);
+    clog_set_level(LOGGER_ID, CLOG_ERROR);
+    gkm_kernel *kernel = gkmkernel_init(&param);
+    gkmkernel_read_problems(kernel, &prob, posfile, negfile);
+    const int N = prob.l;
+    if (N > maxn) return -1;
+    gkmkernel_build_tree(kernel, prob.x, prob.l);
+    for (int i = 0; i < nrows; i++) {
+        if (rows[i] < 0 || rows[i] >= N) return -2;
+        gkmkernel_kernelfunc_batch(kernel, rows[i], (const gkm_data **)prob.x, N, out + (size_t)i * N);
+    }
+    for (int i = 0; i < N; i++) gkmkernel_delete_object(prob.x[i]);
+    free(prob.y); free(prob.x);
+    gkmkernel_destroy(kernel);
+    clog_free(LOGGER_ID);
+    return N;
+}
+
 } /* extern "C" */

@@ -118,12 +118,41 @@ FULL_CONFIGS = {"c2": (5000, 5000, 300, None, 4, 11, 7, 3),
 PEAK_CONFIGS = ("c4",)
 
 
+# (vii) gkmkernel_kernelfunc_batch (src/libgkm.c:1115-1153), the reference's scoring of one sequence against a set
+# (SURVEY.md section 8 row f4): "query" rows scored against every sequence of the problem, support set first.
+# name: (n_support, n_query, length, length_range, [(kernel_type, L, k, d, M, H, gamma), ...])
+BATCH_CASES = {
+    "ragged": (200, 40, None, (60, 700), [(2, 10, 6, 3, 50, 50.0, 1.0), (4, 11, 7, 3, 50, 50.0, 1.0),
+                                          (5, 11, 7, 3, 50, 50.0, 2.0), (4, 12, 8, 4, 50, 50.0, 1.0),
+                                          (0, 8, 4, 4, 50, 50.0, 1.0)]),
+    "fixed300": (120, 24, 300, None, [(4, 11, 7, 3, 50, 50.0, 1.0), (3, 10, 6, 3, 50, 50.0, 2.0)]),
+}
+
+
+def write_batch_rows(tmp):
+    out = {}
+    for name, (nsup, nq, ln, lr, params) in BATCH_CASES.items():
+        pf, nf = os.path.join(tmp, "batch_%s_p.fa" % name), os.path.join(tmp, "batch_%s_n.fa" % name)
+        # the "positive" file is the support set, the "negative" file the queries: rows nsup .. nsup + nq - 1
+        synth.write_problem(pf, nf, nsup, nq, ln or 300, lr)
+        rows = np.arange(nsup, nsup + nq, dtype=np.int32)
+        out[name + "_cfg"] = np.array([nsup, nq, ln or 0, lr[0] if lr else 0, lr[1] if lr else 0])
+        for idx, (t, L, k, d, M, H, g) in enumerate(params):
+            opt = O.make_opt(t, L, k, d, M, H, g, pf, nf, nthreads=1)
+            out["%s_p%d_params" % (name, idx)] = np.array([t, L, k, d, M, H, g], dtype=np.float64)
+            out["%s_p%d_K" % (name, idx)] = O.ref_batch_rows(opt, rows)
+            print("batch rows", name, (t, L, k, d, M, H, g), out["%s_p%d_K" % (name, idx)].shape)
+    np.savez_compressed(os.path.join(HERE, "batch_rows_expected.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c2-full", action="store_true")
     ap.add_argument("--full", action="append", choices=sorted(FULL_CONFIGS),
                     help="full-size digest of a BASELINE configuration through the reference (minutes to an hour)")
     ap.add_argument("--only-full", action="store_true", help="skip the small fixtures")
+    ap.add_argument("--only-batch", action="store_true",
+                    help="only batch_rows_expected.npz (the reference's batch-vs-set scoring entry)")
     ap.add_argument("--threads", type=int, default=os.cpu_count(), help="row threads of the reference for --full")
     args = ap.parse_args()
     if not O.have_ref():
@@ -131,6 +160,10 @@ def main():
 
     tmp = os.path.join(ROOT, "gpurun_out", "golden_tmp")
     os.makedirs(tmp, exist_ok=True)
+    if args.only_batch or not args.only_full:
+        write_batch_rows(tmp)
+    if args.only_batch:
+        return
     if not args.only_full:
         # (i) mismatch weights c_m, bit patterns as hex
         wt = {}

@@ -60,3 +60,24 @@ def synth_codes(n_pos, n_neg, length=300, length_range=None):
     pos = synth.make_sequences(1, n_pos, length, length_range)
     neg = synth.make_sequences(2, n_neg, length, length_range)
     return [encode(s) for s in pos + neg]
+
+
+def batch_rows_expected():
+    """tests/golden/batch_rows_expected.npz: the reference's gkmkernel_kernelfunc_batch (src/libgkm.c:1115-1153) driven
+    by tests/golden/make_golden.py --only-batch.  -> list of dict(name, n_support, n_query, length, length_range,
+    kernel_type, L, k, d, M, H, gamma, K[n_query, n])."""
+    z = np.load(os.path.join(GOLDEN, "batch_rows_expected.npz"))
+    cases = []
+    for key in z.files:
+        if not key.endswith("_cfg"):
+            continue
+        name = key[:-4]
+        nsup, nq, ln, lo, hi = (int(x) for x in z[key])
+        i = 0
+        while "%s_p%d_params" % (name, i) in z:
+            t, L, k, d, M, H, g = z["%s_p%d_params" % (name, i)]
+            cases.append(dict(name="%s_p%d" % (name, i), n_support=nsup, n_query=nq, length=ln or 300,
+                              length_range=(lo, hi) if hi else None, kernel_type=int(t), L=int(L), k=int(k), d=int(d),
+                              M=int(M), H=float(H), gamma=float(g), K=z["%s_p%d_K" % (name, i)]))
+            i += 1
+    return cases

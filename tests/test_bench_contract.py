@@ -108,10 +108,14 @@ def test_gpus_2_under_the_launcher_prints_its_line_on_stdout(built):
     (here two ranks sharing the box's one GPU).  Rank 0 runs the C-ABI child first while the other rank waits, then both
     run the torch.distributed path; ONE line, on STDOUT (round 4's first version left descriptor 1 pointing at stderr
     after run_rank and printed the merged line there)."""
+    import socket
     env = dict(os.environ, GKM_BENCH_SHARE_GPU="1", GKM_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
+    with socket.socket() as sk:      # a free port: the number is also part of the ranks' verdict-file name
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-                        "--master-addr", "127.0.0.1", "--master-port", "29533", os.path.join(ROOT, "bench.py"),
+                        "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
                         "--gpus", "2", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env, stdout=subprocess.PIPE,
                        stderr=subprocess.PIPE, timeout=900)
     d = _one_line(r)
@@ -242,8 +246,10 @@ def test_parity_gate_hashes_the_cells_the_reference_writes(tmp_path, monkeypatch
 
 
 def test_merge_of_the_two_assemblies():
-    """--assembly auto: the C-ABI line is the line; torch is the cross-check; a failed or parity-failing C-ABI child
-    is named in `cabi_error` and the torch numbers take its place."""
+    """--assembly auto: the C-ABI line is the line; torch is the cross-check; a CRASHED or killed C-ABI child is named
+    in `cabi_error` and the torch numbers take its place with exit code 0; a PARITY failure of either assembly keeps
+    the other's numbers but is never silent (parity_failed, exit code 3); a torch launch that ended non-zero never
+    returns 0 with its line."""
     sys.path.insert(0, ROOT)
     import bench
     cabi = {"value": 9.0, "config": {"ranks": 8, "transport": "rccl"}, "roofline": {"allgather_ms": 2.0}, "parity": {"ok": True}}
@@ -252,12 +258,20 @@ def test_merge_of_the_two_assemblies():
     assert rc == 0 and out["value"] == 9.0 and out["also"]["torch_dist"]["value"] == 8.0 and "cabi_error" not in out
     out, rc = bench.merge_assemblies(None, "killed after 300 s", dict(tor), None)
     assert rc == 0 and out["value"] == 8.0 and out["cabi_error"] == "killed after 300 s" and "FALLBACK" in out["assembly"]
+    # the product's matrix is wrong: torch's numbers are kept, but the run FAILS
     out, rc = bench.merge_assemblies(dict(cabi, parity_failed=True, value=None), None, dict(tor), None)
-    assert rc == 0 and out["value"] == 8.0 and "parity" in out["cabi_error"] and out["also"]["cabi"]["value"] is None
+    assert rc == 3 and out["value"] == 8.0 and out["parity_failed"] is True and "parity" in out["cabi_error"] \
+        and out["also"]["cabi"]["value"] is None and out["parity_failed_in"].startswith("gkmhip_gram_allgather")
+    # the cross-check's matrix is wrong while the product's is fine: also a failure
+    out, rc = bench.merge_assemblies(dict(cabi), None, dict(tor, parity_failed=True, value=None), None)
+    assert rc == 3 and out["value"] == 9.0 and out["parity_failed"] is True and "torch" in out["parity_failed_in"]
     out, rc = bench.merge_assemblies(dict(cabi), None, None, "ranks failed")
     assert rc == 0 and out["value"] == 9.0 and out["also"]["torch_dist"] == {"error": "ranks failed"}
-    out, rc = bench.merge_assemblies(None, "x", dict(tor, parity_failed=True, value=None), None)
-    assert rc == 3 and out["value"] is None
+    # a line captured from a launch whose ranks ended non-zero is not a result
+    out, rc = bench.merge_assemblies(None, "killed", dict(tor), "rank 1 exited with code 1", torch_rc=1)
+    assert rc == 1 and out["ranks_failed"] is True and out["value"] == 8.0
+    out, rc = bench.merge_assemblies(dict(cabi), None, dict(tor), "rank 1 exited with code 1", torch_rc=1)
+    assert rc == 1 and out["value"] == 9.0 and out["also"]["torch_dist"]["ranks_exit_code"] == 1
     assert bench.merge_assemblies(None, "x", None, "y") == (None, 1)
     assert bench._strip_flag(["--gpus", "2", "--assembly", "auto", "--check", "--assembly=torch"], "--assembly") == ["--gpus", "2", "--check"]
 

@@ -191,6 +191,40 @@ def test_full_size_against_reference_digest(dev, name):
     assert same, "K differs from the reference in the last bits (still within %g)" % K_TOL
 
 
+@pytest.mark.parametrize("name,nthreads", [("c2", 1), ("c2", 16), ("c4", 1), ("c4", 16)])
+def test_drop_in_call_at_full_size_with_the_reference_callers_geometry(dev, tmp_path, name, nthreads):
+    """gkm_main_pywrapper at N = 10 000 exactly as the reference's Python caller supplies its arguments on EVERY call
+    (scripts/gkmsvm.py:75-77): a FRESH np.zeros((15000, 15000)) -- untouched pages --, row r at byte 120 000 r, -@ 1
+    (gkmQC's default) and 16.  The strict lower triangle must have the SHA-256 of the reference's own matrix
+    (tests/golden/c2_full_digest.npz / c4_full_digest.npz: configs[1], the configs[3] stand-in), the diagonal 1.0,
+    everything else -- the upper triangle, rows and columns >= N -- must be as the caller left it (zero)."""
+    from gkmqc_amd import synth
+    z = np.load(os.path.join(helpers.GOLDEN, name + "_full_digest.npz"))
+    npos, nneg, ln, lr, t, L, k, d = FULL_CONFIGS[name]
+    n = npos + nneg
+    pf, nf = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+    if name == "c4":
+        synth.write_peak_problem(pf, nf, npos, nneg, ln)
+    else:
+        synth.write_problem(pf, nf, npos, nneg, ln or 300, lr)
+    cap = 15000
+    kmat = np.zeros((cap, cap))
+    assert kmat.strides == (120000, 8)
+    rows = (kmat.ctypes.data + np.arange(cap) * kmat.strides[0]).astype(np.uintp)
+    sizes = np.full(2, -1, dtype=np.int32)
+    opt = dev.gkmOpt(t, L, k, d, 50, 50.0, 1.0, pf.encode(), nf.encode(), nthreads, 0)
+    rc = dev.load().gkm_main_pywrapper(ctypes.byref(opt), rows.ctypes.data, sizes.ctypes.data)
+    assert rc == 0 and tuple(sizes) == (npos, nneg)
+    h = hashlib.sha256()
+    for a in range(1, n):
+        h.update(memoryview(kmat[a, :a]))
+    assert h.digest() == z["sha256"].tobytes(), "the drop-in call's lower triangle is not the reference's"
+    assert (np.diagonal(kmat)[:n] == 1.0).all() and not np.diagonal(kmat)[n:].any()
+    assert not kmat[n:].any() and not kmat[:n, n:].any(), "rows / columns >= N were written"
+    for a in range(n):
+        assert not kmat[a, a + 1:n].any(), "upper triangle written in row %d" % a
+
+
 def _oracle_profiles(seqs, t, L, k, d, M=50, H=50.0):
     from oracle import oracle as O
     opt = O.make_opt(t, L, k, d, M, H)
@@ -424,6 +458,34 @@ def test_rectangular_kernel_and_self_norms(dev, kernel):
         assert (got[i] == Ksym[a]).all(), a
 
 
+@pytest.mark.parametrize("kernel", ["bitslice", "direct"])
+def test_scoring_against_a_set_matches_the_reference(dev, kernel):
+    """SURVEY.md section 8 row f4, the batch-vs-set half: gkmhip_self_norms + gkmhip_gram_rows_full +
+    gkmhip_normalize_rows_full (device.cross_kernel) against OUTPUT OF THE REFERENCE's gkmkernel_kernelfunc_batch
+    (src/libgkm.c:1115-1153; tests/golden/batch_rows_expected.npz, made by make_golden.py --only-batch from the
+    compiled reference): 40 query rows x 240 sequences of 60-700 bp (types 2, 4, 5, 0; L 8-12; d 3-4) and 24 x 144
+    fixed-length ones (types 4 and 3 = RBF).  Off the diagonal the values must be IDENTICAL (same integer profiles,
+    same fp64 operation order: sum over m ascending, product of the norms first, one division, libgkm.c:576-582,
+    1140-1143; the RBF types pass through the device's exp(): 1e-12); on the diagonal the reference's entry leaves G / sqnorm^2 (1.0 to rounding) where this build writes
+    1.0 as gkm_main_pywrapper does (gkmkern_pylib.c:218-221)."""
+    kern = dev.KERNEL_BITSLICE if kernel == "bitslice" else dev.KERNEL_DIRECT
+    for c in helpers.batch_rows_expected():
+        seqs = helpers.synth_codes(c["n_support"], c["n_query"], c["length"], c["length_range"])
+        rows = list(range(c["n_support"], c["n_support"] + c["n_query"]))
+        got = dev.cross_kernel(seqs, rows, c["kernel_type"], c["L"], c["k"], c["d"], c["M"], c["H"], c["gamma"],
+                               kernel=kern)
+        K = got["K"].cpu().numpy()
+        assert K.shape == c["K"].shape, c["name"]
+        for i, a in enumerate(rows):
+            off = np.arange(K.shape[1]) != a
+            err = helpers.max_rel_err(K[i][off], c["K"][i][off])
+            if c["kernel_type"] in (3, 5):    # RBF: exp() of the device against the host's libm, a few ulp
+                assert err < 1e-12, (c["name"], a, err)
+            else:
+                assert np.array_equal(K[i][off], c["K"][i][off]), (c["name"], a, err)
+            assert K[i][a] == 1.0 and abs(c["K"][i][a] - 1.0) < 1e-12
+
+
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
 def test_boundary_over_several_device_contexts(dev, monkeypatch, devices):
     """GKM_DEVICES: the boundary call spreads row blocks over one context + host thread per listed
@@ -498,6 +560,44 @@ def test_one_process_multi_gpu_assembly(dev, quirk_seqs, nctx, chunks):
             assert torch.equal(K, one), "assembled matrix differs from the single-GPU matrix"
         low = dev.gram_matrix_multi(problem, t, L, k, d, gamma=2.0, devices=[0] * nctx, symmetric=False, chunks=chunks)
         assert torch.equal(low["K"][nctx - 1], torch.tril(one))
+
+
+@pytest.mark.parametrize("nctx,chunks", [(2, 0), (4, 3)])
+def test_one_rank_alone_reassembles_the_matrix(dev, nctx, chunks):
+    """gkmhip_gram_rank_alone (the measurement entry behind tools/rank_alone.py and DESIGN.md section 7's table): after a
+    gkmhip_gram_allgather over `nctx` contexts, every rank g re-runs ITS step alone -- its chunks into its packed slab,
+    the slab into its gathered buffer, un-permute + normalise of the whole matrix -- and must leave the same matrix,
+    bit for bit, in a zeroed K; without the earlier call (no gathered slabs of that shape) it must refuse."""
+    import torch
+    problem = helpers.synth_codes(200, 180, 300, (150, 420))
+    t, L, k, d = 4, 11, 7, 3
+    one = torch.tril(dev.gram_matrix(problem, t, L, k, d)["K"])
+    lib = dev.load()
+    n = len(problem)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctxs = [dev.GramContext(t, L, k, d, 50, 50.0, 1.0, 0) for _ in range(nctx)]
+    try:
+        for c in ctxs:
+            c.set_sequences(problem, stream)
+        Ks = [torch.zeros((n, n), dtype=torch.float64, device="cuda") for _ in range(nctx)]
+        out6 = np.zeros(6)
+        lib.gkmhip_release_comms()
+        assert lib.gkmhip_gram_rank_alone(ctxs[0].handle, 0, nctx, chunks, Ks[0].data_ptr(), n, 0, out6.ctypes.data) != 0
+        handles = (ctypes.c_void_p * nctx)(*[c.handle for c in ctxs])
+        outs = (ctypes.c_void_p * nctx)(*[K.data_ptr() for K in Ks])
+        assert lib.gkmhip_gram_allgather(handles, nctx, outs, n, 0, chunks) == 0
+        for g in range(nctx):
+            assert torch.equal(Ks[g], one)
+            Ks[g].zero_()
+            torch.cuda.synchronize()
+            rc = lib.gkmhip_gram_rank_alone(ctxs[g].handle, g, nctx, chunks, Ks[g].data_ptr(), n, 0, out6.ctypes.data)
+            assert rc == 0, lib.gkmhip_last_error().decode()
+            assert torch.equal(Ks[g], one), "rank %d alone" % g
+            assert out6[0] > 0 and out6[1] > 0 and out6[3] > 0 and out6[4] > 0 and int(out6[5]) >= 2
+    finally:
+        for c in ctxs:
+            c.close()
+        lib.gkmhip_release_comms()
 
 
 @pytest.mark.parametrize("chunk", ["8", "40", "64"])

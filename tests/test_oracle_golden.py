@@ -114,3 +114,26 @@ def test_oracle_vs_live_reference(O, tmp_path):
         rc, kref, _, _ = O.ref_pywrapper(opt, ref["n"])
         assert rc == 0
         assert helpers.max_rel_err(helpers.tril_pack(mine["K"]), helpers.tril_pack(kref)) < 1e-12
+
+
+def test_batch_rows_fixture_is_the_symmetric_completion(O, tmp_path):
+    """The reference's batch-vs-set entry (gkmkernel_kernelfunc_batch, src/libgkm.c:1115-1153; fixture made by
+    tests/golden/make_golden.py --only-batch) scores a row against EVERY sequence of the problem: its values are the
+    symmetric completion of the triangle that gkm_main_pywrapper writes -- checked here with the CPU restatement, so
+    that the GPU test of gkmhip_gram_rows_full compares with reference output whose meaning is pinned."""
+    from gkmqc_amd import synth
+    for c in helpers.batch_rows_expected():
+        if c["name"] not in ("ragged_p1", "fixed300_p1"):     # one weighted and one RBF case: the oracle is brute force
+            continue
+        pf, nf = str(tmp_path / "p.fa"), str(tmp_path / "n.fa")
+        synth.write_problem(pf, nf, c["n_support"], c["n_query"], c["length"], c["length_range"])
+        opt = O.make_opt(c["kernel_type"], c["L"], c["k"], c["d"], c["M"], c["H"], c["gamma"], pf, nf)
+        r = O.gram(opt, want_profiles=False, nthreads=8)
+        K = np.tril(r["K"], -1) + np.tril(r["K"], -1).T
+        n = r["n"]
+        assert c["K"].shape == (c["n_query"], n)
+        for i in range(c["n_query"]):
+            a = c["n_support"] + i
+            off = np.arange(n) != a
+            assert helpers.max_rel_err(c["K"][i][off], K[a][off]) < 1e-12, (c["name"], a)
+            assert abs(c["K"][i][a] - 1.0) < 1e-12      # G / sqnorm^2, not forced to 1.0 by this entry
