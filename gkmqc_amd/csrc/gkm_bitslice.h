@@ -510,13 +510,19 @@ GKM_HD HitValue resolve_hit_packed(int b, int w, int delta, int strand, uint32_t
  * v_alignbit, v_ffbl, v_bcnt, compares, SDWA -- every ~4.2; an SGPR operand costs a stream made of nothing else 4.2 too,
  * but nothing in a mix with VGPR-only instructions: 2.2 is what tools/issue_model.py prices it at):
  *   bits  0..3   word index w within the shift (0..W-1; a trip adds the word's offset in its group)       ms & 15
- *   bit   4      strand (0 forward, 1 reverse complement): (ms >> 2) & 4 is the byte offset of the strand's word
- *                in the interleaved column image in LDS
- *   bit   5      strand & [the column has an even number of l-mers]: the reverse strand's weights are the forward
- *                ones mirrored, wt_rc[q] = wt[nB-1-q] = wd[|q + even - nB/2|] (libgkm.c:924)
+ *   bit   4      strand (0 forward, 1 reverse complement), bit 5: strand & [the column has an even number of l-mers]
+ *                (the reverse strand's weights are the forward ones mirrored, wt_rc[q] = wt[nB-1-q] = wd[|q + even -
+ *                nB/2|], libgkm.c:924) -- used by the CPU model of the hit path (bitslice_cpu_probe.cpp) only: since
+ *                round 5 the kernel empties its hit list between the two strands, the strand is wave-uniform inside a
+ *                trip and the kernel leaves both bits 0
  *   bits  7..12  source lane; ms & 0x1F80 is the byte offset of that lane's packed positions (128 bytes per lane)
- *   bits 21..31  shift delta (0..2046): ms >> 21 */
+ *   bits 21..31  shift delta (0..2046): ms >> 21
+ *   (k_gram_bitslice's same-length variant also keeps, set once per wave by the source lane:
+ *   bits  4..6   piece index of the lane within its row (the lane holds sequence positions pi * capacity ..)
+ *   bits 13..18  row slot of the lane; (ms >> 11) & 0xFC is its byte offset in a profile row) */
 constexpr uint32_t META_LANE_SHIFT = 7;
+constexpr uint32_t META_PIECE_SHIFT = 4;
+constexpr uint32_t META_SLOT_SHIFT = 13;
 GKM_HD uint32_t pack_meta(int delta, int w, int strand, int even_adj = 0)
 {
     return (uint32_t)w | ((uint32_t)strand << 4) | ((uint32_t)(strand & even_adj) << 5) | ((uint32_t)delta << 21);

@@ -271,6 +271,7 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     ctx->h_lmoff[0] = 0;
     ctx->h_cum_n[0] = 0.0;
     ctx->maxlen = 0;
+    ctx->minlen = 1 << 30;
     for (int i = 0; i < n; i++) {
         const int64_t len = offsets[i + 1] - offsets[i];
         if (len < L) return set_err_msg("sequence " + std::to_string(i) + " is shorter than L", 3);
@@ -279,6 +280,7 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
         ctx->h_lmoff[(size_t)i + 1] = ctx->h_lmoff[(size_t)i] + (len - L + 1);
         ctx->h_cum_n[(size_t)i + 1] = ctx->h_cum_n[(size_t)i] + (double)(len - L + 1);
         ctx->maxlen = std::max(ctx->maxlen, (int)len);
+        ctx->minlen = std::min(ctx->minlen, (int)len);
     }
     ctx->n = n;
     if (weighted && (wdist_len <= (ctx->maxlen - L + 1) / 2 || wdist_len > WD_LDS))

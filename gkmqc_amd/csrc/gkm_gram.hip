@@ -262,10 +262,21 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
          * kernel depend on its occupancy? */
         const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
-        /* dynamic LDS of a wave: the column's two packed strands + its weight bytes by position with L - 1 zeros either side */
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw + (ctx->maxlen + L - 1 + 3) / 4) * sizeof(uint32_t) + lds_pad;
+        /* dynamic LDS of a wave: the column's two packed strands + the weight bytes.  One-piece variants: the column's
+         * weights by position with L - 1 zeros either side (k_gram_bitslice POSTAB), plus a copy of the distance table for
+         * the row side unless every sequence has the same length; several-pieces variants: the distance table alone. */
+        const size_t wd_bytes = (size_t)((ctx->wd_len + 3) / 4) * 4;
+        const size_t postab_bytes = (size_t)((ctx->maxlen + L - 1 + 3) / 4) * 4;
+        const bool same_length = ctx->minlen == ctx->maxlen;
+        const int row_wtab = same_length ? -1 : (int)postab_bytes;
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
+                               (packed ? wd_bytes : postab_bytes + (same_length ? 0 : wd_bytes));
+        static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
+        /* same-length problems, one piece per lane: the variant that needs neither piece table nor permute (PK = 4) */
+        const bool unif = !packed && same_length && getenv("GKM_NO_UNIF") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
+        if (unif) bs = gkm_pick_bitslice(4, L, d);
         bool bperm = false;
-        if (!packed) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
+        if (!packed && !unif) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
             hipFuncAttributes fa, fb;
             const char *force = getenv("GKM_FORCE_BPERM");
             bs_kernel_t bsp = gkm_pick_bitslice(3, L, d);
@@ -296,6 +307,14 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
             if (packed) {
                 lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
+            } else if (unif) {
+                /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index
+                 * is the piece's first position over the lane capacity: pieces of a same-length problem fill whole lanes */
+                const int cap = gkmbs::segment_capacity(W, L);
+                if (pc.b0 != 0 || pc.p0 % cap != 0 || pc.p0 / cap > 7 || slot4 / 4 > 63)
+                    return set_err_msg("gram: same-length packing broke its own rule", 2);
+                lane_piece[(size_t)pc.lane * 2] = ((slot4 / 4u) << gkmbs::META_SLOT_SHIFT) |
+                                                  ((uint32_t)(pc.p0 / cap) << gkmbs::META_PIECE_SHIFT);
             } else {
                 lane_piece[(size_t)pc.lane * 2] = slot4;
                 lane_piece[(size_t)pc.lane * 2 + 1] = c0b;
@@ -413,7 +432,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
         A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
-        A.rpw = rpw; A.pkw = ctx->pkw;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.row_wtab = row_wtab;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
@@ -456,7 +475,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                 fprintf(stderr, "gkmhip: hot kernel: %d VGPRs, %zu + %zu bytes of LDS per wave, %d one-wave workgroups per CU\n",
                         fa.numRegs, (size_t)fa.sharedSizeBytes, dyn_lds, per_cu);
         }
-        ctx->last_kernel = bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+        ctx->last_kernel = unif ? "k_gram_bitslice<same length>" : bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;

@@ -95,6 +95,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
      *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
     constexpr bool PACKED = PK == 1 || PK == 2;
     constexpr bool BPERM = PK == 3;
+    /*      4: as 0, for problems whose sequences all have the SAME length (every fixed-length data set: gkmQC's own
+     *         5 000 x 600 bp subsets, BASELINE configs 1-3): a row then takes k = ceil(windows / 311) whole lanes, piece
+     *         pi of it starts at sequence position pi * capacity, and all a trip needs of the source lane -- its row slot
+     *         and pi -- rides in the record's origin word (9 spare bits, set once per wave): no piece table, no permute,
+     *         and the row l-mer's weight comes from the column's own table by position (same length, same weights).
+     *         Round 5: an LDS operation in a trip costs what three VALU instructions do (sensitivity probes,
+     *         profiles/r5_trip_sensitivity.txt); this variant has two fewer than 3 and one LDS round trip less. */
+    constexpr bool UNIF = PK == 4;
     /* (The ablation builds of rounds 1-3 -- parts of this kernel skipped to time the rest, results wrong -- lived
      * here as a fifth template parameter; they are gone from the source since round 4.  tools/variants.sh rebuilds
      * them from revision a4bed73, profiles/r2_ablation_timings.txt and r2_pmc_ablation_builds*.txt hold what they
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = (BS_GRP + 1) * BS_CAP, LMASK_WORDS = PACKED ? 64 : 0;
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
-    constexpr int LPIECE_WORDS = PACKED ? 64 * NP : BPERM ? 0 : 128;
+    constexpr int LPIECE_WORDS = PACKED ? 64 * NP : (BPERM || UNIF) ? 0 : 128;
     constexpr int STATIC_WORDS = ACC_WORDS + LIST_WORDS + LMASK_WORDS + LPIECE_WORDS;
     __shared__ uint32_t s_mem[STATIC_WORDS];
     uint32_t *const accl = s_mem; /* mismatch profiles [m][row slot] */
@@ -139,6 +147,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     static_assert((ACC_WORDS * 4) % 256 == 0, "the list's arrays stay 64-dword aligned (ds_write2st64_b32)");
     /* an add at accl[m <= L][slot] stays inside the static LDS (everywhere but 128 slots with d <= 1) */
     constexpr bool M_FITS = (L + 1) * NSLOT <= STATIC_WORDS;
+    /* (the dynamic LDS follows the static LDS: the column image's address is STATIC_WORDS * 4) */
+    constexpr bool COL_BASE_FOLDS = (STATIC_WORDS * 4) % 1024 == 0;
     static_assert(W % BS_GRP == 0, "a shift is a whole number of record groups");
     /* The list is a STACK (round 3; a ring before): a trip is due as soon as it holds BS_TRIP records and it is checked
      * after every group (at most 64 new records); a trip takes the BS_TRIP records on TOP and puts at most as many back:
@@ -193,7 +203,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
     if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
     constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
-    if (!BPERM) {
+    if (!BPERM && !UNIF) {
 #pragma unroll
         for (int k = 0; k < LPW; k++) lpiece[lane * LPW + k] = A.lane_piece[(size_t)(tile * 64 + lane) * LPW + k];
     }
@@ -204,11 +214,17 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
     uint32_t my_both = 0u; /* row slot * 4 (< 256) | biased centre offset (< 8192) << 16 */
     if (BPERM)
         my_both = A.lane_piece[(size_t)(tile * 64 + lane) * 2] | (A.lane_piece[(size_t)(tile * 64 + lane) * 2 + 1] << 16);
-    const uint32_t lane_tag = (uint32_t)lane << META_LANE_SHIFT, lane4 = (uint32_t)lane << 2;
+    /* (UNIF: word 0 of the lane's piece entry holds its row slot and piece index where the origin word wants them) */
+    const uint32_t lane_tag = ((uint32_t)lane << META_LANE_SHIFT) | (UNIF ? A.lane_piece[(size_t)(tile * 64 + lane) * 2] : 0u);
+    const uint32_t lane4 = (uint32_t)lane << 2;
     const int pkw = A.pkw;
-    /* dynamic LDS: the column's two packed strands first, interleaved word by word, the column's weight bytes behind them */
+    /* dynamic LDS: the column's two packed strands first, interleaved word by word, the weight bytes behind them */
     uint32_t *const s_col = s_dyn;
-    uint8_t *const s_wcol = (uint8_t *)(s_dyn + 2 * pkw);
+    uint8_t *const s_wtab = (uint8_t *)(s_dyn + 2 * pkw);
+    /* POSTAB (the one-piece-per-lane variants): the COLUMN's weights sit in LDS by l-mer position with L - 1 zero bytes
+     * either side, which rids a trip of its two tests (below); the several-pieces variants keep the distance-indexed
+     * table for both sides and the tests -- their LDS has no room for T + L - 1 more bytes without losing a wave. */
+    constexpr bool POSTAB = !PACKED;
     /* this tile's packed lanes: 32-bit byte offsets from a wave-uniform base (global_load with an SGPR
      * base instead of a 64-bit address computed per lane); 128 bytes per lane, so that the lane field of a
      * record's origin word IS the lane's byte offset */
@@ -219,25 +235,42 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         const int nB = T - L + 1;
         const uint32_t rcpT = mod_magic((uint32_t)T);
         for (int x = lane; x < 2 * pkw; x += 64) s_col[x] = A.colpk[(size_t)j * 2 * pkw + x];
-        /* The column's positional weights BY POSITION, L - 1 zero bytes either side: s_wcol[L - 1 + p] = wt[p] =
-         * wd[|nB/2 - p|] for the l-mers p < nB (libgkm.c:912-925).  A forward-strand window q reads s_wcol[L - 1 + q]; the
-         * reverse strand's weights are the forward ones mirrored, wt_rc[q] = wt[nB-1-q] (libgkm.c:924), so it reads
-         * s_wcol[L - 1 + nB - 1 - q].  The windows that wrap around the end of the strand (q = nB .. T - 1: not l-mers,
-         * gkm_bitslice.h window_hits) land in the zero bytes behind / before the table: they add 0 to some profile
-         * word and need no test.  (Round 5; before, a distance-indexed table served both sides and a trip compared
-         * q with nB: the table by position is what makes the zeros possible -- |nB/2 - q| of q = nB equals that of
-         * q = 0 when nB is even.) */
+        /* Weights.  wd[D] = weight of an l-mer at distance D from its sequence's centre l-mer (libgkm.c:912-925 depends on
+         * nothing else; ones for the unweighted kernel types), 1 KB in global memory.
+         * POSTAB: the column's weights BY POSITION, s_wtab[L - 1 + p] = wt[p] = wd[|nB/2 - p|] for the l-mers p < nB,
+         * L - 1 zero bytes either side.  A forward-strand window q reads s_wtab[L - 1 + q]; the reverse strand's weights
+         * are the forward ones mirrored, wt_rc[q] = wt[nB-1-q] (libgkm.c:924): s_wtab[L - 1 + nB - 1 - q].  The windows
+         * that wrap around the end of the strand (q = nB .. T - 1: not l-mers, gkm_bitslice.h window_hits) land in the
+         * zero bytes behind / before the table: they add 0 to some profile word and need no test.  (A distance-indexed
+         * table cannot do that: |nB/2 - q| of q = nB equals that of q = 0 when nB is even.)  The ROW side reads
+         * wd[|c0 - i0|]: from the right half of the very same table when every sequence of the problem has the same
+         * length (A.row_wtab < 0: no row's distance exceeds the column's nB - 1 - nB/2), else from a copy of wd behind
+         * it, at byte A.row_wtab of the weight area.
+         * !POSTAB: one distance-indexed table for both sides, as rounds 2-4 had it. */
         const uint32_t ccen = (uint32_t)(nB / 2);
-        for (int x = lane; x < T + L - 1; x += 64) {
-            const int p = x - (L - 1), dd = (int)ccen - p;
-            s_wcol[x] = (p >= 0 && p < nB) ? A.wd8[dd < 0 ? -dd : dd] : (uint8_t)0;
+        uint32_t s_rowbase; /* LDS byte offset (from s_dyn) of the row side's wd[0] */
+        if (POSTAB) {
+            for (int x = lane; x < T + L - 1; x += 64) {
+                const int p = x - (L - 1), dd = (int)ccen - p;
+                s_wtab[x] = (p >= 0 && p < nB) ? A.wd8[dd < 0 ? -dd : dd] : (uint8_t)0;
+            }
+            if (!UNIF && A.row_wtab >= 0)
+                for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.row_wtab))[x] = ((const uint32_t *)A.wd8)[x];
+            if (UNIF) s_rowbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1);      /* by position */
+            else s_rowbase = (uint32_t)pkw * 8u + (A.row_wtab >= 0 ? (uint32_t)A.row_wtab : (uint32_t)(L - 1) + ccen);
+        } else {
+            for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)s_wtab)[x] = ((const uint32_t *)A.wd8)[x];
+            s_rowbase = (uint32_t)pkw * 8u;
         }
         /* strand-uniform scalars of the hit path (set at the top of each strand's sweep; the list is emptied between
          * the strands, so a trip only ever holds records of ONE strand and the strand costs it no instruction):
          *   s_strand4   byte offset of the strand's words in the interleaved column image (0 / 4)
-         *   s_wsign     0 / ~0: the weight index is (q ^ s_wsign) + s_wbase = L-1 + q  or  L-1 + nB-1 - q, plus the
-         *               table's byte offset in the dynamic LDS */
+         *   POSTAB:  s_wsign 0 / ~0, s_wbase: the column weight's LDS byte is (q ^ s_wsign) + s_wbase = L-1 + q or
+         *            L-1 + nB-1 - q behind the table's start
+         *   !POSTAB: s_wbase = [reverse strand and nB even]: wt_rc[q] = wt[nB-1-q] = wd[|q + [nB even] - nB/2|] */
         uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u;
+        uint32_t v_rowbase = 0u;
+        if (!POSTAB) asm volatile("v_mov_b32 %0, %1" : "=v"(v_rowbase) : "s"(s_rowbase));
 #pragma unroll
         for (int m = 0; m <= D; m++)
             for (int rs = lane; rs < (two_copies ? NSLOT : nrows); rs += 64) accl[m * NSLOT + rs] = 0u;
@@ -257,12 +290,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
             const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
             const int k = PACKED ? piece_of_bitrow(*(const uint32_t *)((const char *)lmask + (PACKED ? (lane128 >> 5) : 0u)), (int)bit) : 0;
-            uint32_t slot4, c0b; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
+            uint32_t slot4, c0b = 0u; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
             if (PACKED) {
                 static_assert(!PACKED || NP == 4, "lpiece is addressed as lane * 16 + piece * 4");
                 const uint32_t lp = *(const uint32_t *)((const char *)lpiece + ((lane128 >> 3) + ((uint32_t)k << 2)));
                 slot4 = lp & 0xFFFFu;
                 c0b = lp >> 16;
+            } else if (UNIF) {
+                slot4 = (ms >> (META_SLOT_SHIFT - 2)) & 0xFCu;
             } else if (BPERM) {
                 slot4 = pslot4;
                 c0b = pc0b;
@@ -276,21 +311,39 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             uint32_t q;
             if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
             else q = mod_small(x, (uint32_t)T, rcpT);
-            /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
-            const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
-            const uint32_t *cw = (const uint32_t *)((const char *)s_col + lop3<0xEA>(q >> 1, ~7u, s_strand4));
-            const uint32_t wa = A.wd8[absdiff(c0b, i0 | 2048u)];
-            const uint32_t wb = ((const uint8_t *)s_dyn)[(q ^ s_wsign) + s_wbase];
-            /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
-            const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
-            const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
-            const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
-            /* No test for m <= D and none for a wrapped column window: a window that is an l-mer on both sides has the m
-             * the counting loop found (<= D); one that wraps around the end of the strand (packed strands: zeros behind
-             * the end, so any m <= L) has wb = 0 and adds nothing, wherever m * NSLOT + slot lies in the static LDS
-             * (M_FITS).  LDS atomic: ds_add_u32. */
-            if (M_FITS || m <= (uint32_t)D)
-                atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+            /* a window that wraps around the end of the strand is not an l-mer (gkm_bitslice.h window_hits); POSTAB: its
+             * weight is 0 */
+            if (POSTAB || (int)q < nB) {
+                /* (a & -4) | b and (a & -8) | b as ONE v_bitop3_b32 each (truth table 0xEA), inline constants */
+                const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+                /* the column image starts where the static LDS ends; where that is a multiple of 1 024 bytes (d = 3) the
+                 * word offset (q / 16 * 8 < 1 024) and the base share no bit and the base rides in the same v_bitop3_b32 */
+                typedef const uint32_t __attribute__((address_space(3))) *lds_words; /* (a 32-bit LDS address) */
+                const uint32_t cwo = lop3<0xEA>(q >> 1, ~7u, s_strand4);
+                const lds_words cw = COL_BASE_FOLDS ? (lds_words)(uintptr_t)cwo : (lds_words)(uintptr_t)((uint32_t)(STATIC_WORDS * 4) + cwo);
+                const uint8_t *wdb = (const uint8_t *)s_dyn;
+                /* (the table's offset rides in the third operand of the v_sad_u32 that forms the index) */
+                uint32_t wa, wb;
+                if (UNIF) { /* the row l-mer is l-mer pi * capacity + i0 of a sequence as long as the column */
+                    wa = wdb[__umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)segment_capacity(W, L)) + i0 + s_rowbase];
+                    wb = wdb[(q ^ s_wsign) + s_wbase];
+                } else if (POSTAB) {
+                    wa = wdb[__usad(c0b, i0 | 2048u, s_rowbase)];
+                    wb = wdb[(q ^ s_wsign) + s_wbase];
+                } else { /* (the table's offset in a VGPR: |q - centre| + offset would name two SGPRs in one v_sad_u32) */
+                    wa = wdb[__usad(c0b, i0 | 2048u, v_rowbase)];
+                    wb = wdb[__usad(q + s_wbase, ccen, v_rowbase)];
+                }
+                /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
+                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
+                const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
+                const uint32_t m = (uint32_t)pk_mismatch(ea, eb, L);
+                /* POSTAB: no test for m <= D either.  A window that is an l-mer on both sides has the m the counting loop
+                 * found (<= D); one that wraps (packed strands: zeros behind the end, so any m <= L) has wb = 0 and adds
+                 * nothing, wherever m * NSLOT + slot lies in the static LDS (M_FITS).  LDS atomic: ds_add_u32. */
+                if ((POSTAB && M_FITS) || m <= (uint32_t)D)
+                    atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+            }
         };
 
         /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
@@ -398,9 +451,10 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         };
 
         for (int strand = 0; strand < 2; strand++) {
-            s_strand4 = (uint32_t)strand * 4u;
+            s_strand4 = (uint32_t)strand * 4u + (COL_BASE_FOLDS ? (uint32_t)(STATIC_WORDS * 4) : 0u);
             s_wsign = strand ? ~0u : 0u;
-            s_wbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u); /* ~q = -q - 1 */
+            if (POSTAB) s_wbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u); /* ~q = -q - 1 */
+            else s_wbase = (strand && !(nB & 1)) ? 1u : 0u;
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
             const sgpr_words sbh = (sgpr_words)(A.sb + ((size_t)(j * 2 + strand) * 2) * A.xw);
@@ -504,6 +558,7 @@ bs_kernel_t gkm_pick_bitslice(int pk, int L, int d)
     case 1: return pick_bitslice<10, 1>(L, d);
     case 2: return pick_bitslice<10, 2>(L, d);
     case 3: return pick_bitslice<10, 3>(L, d);
+    case 4: return pick_bitslice<10, 4>(L, d);
     }
     return nullptr;
 }

@@ -33,6 +33,7 @@
 #include "gkm_pack.h"
 
 #define GKM_MAXD1 13 /* d <= 12 */
+#define GKM_MAXLEN 2047 /* longest sequence (the reference truncates there: libgkm.h:29-34, libgkm.c:1286-1291) */
 #define GKM_SCRATCH_SLOTS 2 /* per-launch scratch sets of a context (gkmhip_set_scratch_slot) */
 
 /* ------------------------------------------------------------------ errors (gkm_context.hip) */
@@ -89,7 +90,7 @@ struct gkmhip_ctx {
     int L = 0, d = 0, rbf = 0, kernel_pref = GKMHIP_KERNEL_AUTO;
     double c[GKM_MAXD1] = {0};
     double gamma = 1.0;
-    int n = 0, weighted = 0, maxlen = 0;
+    int n = 0, weighted = 0, maxlen = 0, minlen = 0;
     std::vector<int> h_len;
     std::vector<int64_t> h_lmoff;
     std::vector<double> h_cum_n; /* prefix sums of n_j = len_j - L + 1 */
