@@ -171,7 +171,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     /* (hipFree waits for the work that may still use the buffers; no separate device-wide wait) */
     ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
-    ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release();
+    ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release(); ctx->postab.release();
     for (auto &scr : ctx->scratch) scr.release();
     ctx->sq.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -236,6 +236,24 @@ __global__ void k_pack_strands(const uint8_t *__restrict__ codes, const int64_t 
         colpk[((size_t)s * pkw + x) * 2 + strand] = gkmbs::pk_word(seq, T, strand, x);
 }
 
+/* one workgroup per sequence: its positional weights as the hit path's column side wants them in LDS -- byte L - 1 + p =
+ * wt[p] = wd[|n/2 - p|] for the l-mers p < n (libgkm.c:912-925), zero bytes before (L - 1 of them) and behind (to the end of
+ * the ptw words): a window that wraps around the end of the strand reads a zero (k_gram_bitslice POSTAB) */
+__global__ void k_build_postab(const int64_t *__restrict__ off, int L, const uint8_t *__restrict__ wd, int ptw,
+                               uint32_t *__restrict__ postab)
+{
+    const int s = blockIdx.x;
+    const int n = (int)(off[s + 1] - off[s]) - L + 1;
+    for (int x = threadIdx.x; x < ptw; x += blockDim.x) {
+        uint32_t v = 0u;
+        for (int b = 0; b < 4; b++) {
+            const int p = x * 4 + b - (L - 1), dd = n / 2 - p;
+            if (p >= 0 && p < n) v |= (uint32_t)wd[dd < 0 ? -dd : dd] << (8 * b);
+        }
+        postab[(size_t)s * ptw + x] = v;
+    }
+}
+
 /* grid (sequence*2+strand, plane); threads over words of the strand's SB table */
 __global__ void k_build_sb(const uint8_t *__restrict__ codes, const int64_t *__restrict__ off, int W,
                            int L, int xw, uint32_t *__restrict__ sb)
@@ -263,6 +281,7 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     ctx->have_lmers = false;
     ctx->have_sb = false;
     ctx->have_colpk = false;
+    ctx->have_postab = false;
     ctx->n = 0;
     ctx->weighted = weighted;
     ctx->h_len.resize((size_t)n);
@@ -303,7 +322,7 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
      * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
      * second launch on the other stream before it was complete (found when the host stopped waiting for its
      * uploads: the config-4 stand-in through two contexts differed in a few hundred rows). */
-    if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream))) return 4;
+    if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream))) return 4;
     if (!bitslice_serves(ctx) && ensure_lmers(ctx, stream)) return 4;
     /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
      * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
@@ -340,6 +359,20 @@ int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
     ctx->pkw = pkw;
     HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_colpk = true;
+    return 0;
+}
+
+int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream)
+{
+    if (ctx->have_postab) return 0;
+    const int ptw = (ctx->maxlen + ctx->L - 1 + 3) / 4;
+    if (ctx->postab.ensure((size_t)ctx->n * (size_t)ptw)) return 4;
+    hipLaunchKernelGGL(k_build_postab, dim3((unsigned)ctx->n), dim3(64), 0, stream, ctx->off.p, ctx->L, ctx->wd.p, ptw,
+                       ctx->postab.p);
+    HIPCHK(hipGetLastError());
+    ctx->ptw = ptw;
+    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    ctx->have_postab = true;
     return 0;
 }
 

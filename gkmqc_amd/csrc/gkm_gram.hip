@@ -258,22 +258,22 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
         bs_kernel_t bs = !packed ? gkm_pick_bitslice(0, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
         /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
-        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream)) return 4;
+        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream)) return 4;
         /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
          * kernel depend on its occupancy? */
         const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
         /* dynamic LDS of a wave: the column's two packed strands + the weight bytes.  One-piece variants: the column's
-         * weights by position with L - 1 zeros either side (k_gram_bitslice POSTAB), plus a copy of the distance table for
-         * the row side unless every sequence has the same length; several-pieces variants: the distance table alone. */
+         * weights by position with zeros either side (ctx->ptw words, k_gram_bitslice POSTAB), and behind them a copy of
+         * the distance table for the row side unless every sequence has the same length (PK = 4: the rows read the
+         * column's table by position); several-pieces variants: the distance table alone. */
         const size_t wd_bytes = (size_t)((ctx->wd_len + 3) / 4) * 4;
-        const size_t postab_bytes = (size_t)((ctx->maxlen + L - 1 + 3) / 4) * 4;
+        const size_t postab_bytes = (size_t)ctx->ptw * 4;
         const bool same_length = ctx->minlen == ctx->maxlen;
-        const int row_wtab = same_length ? -1 : (int)postab_bytes;
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
-                               (packed ? wd_bytes : postab_bytes + (same_length ? 0 : wd_bytes));
-        static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
         /* same-length problems, one piece per lane: the variant that needs neither piece table nor permute (PK = 4) */
         const bool unif = !packed && same_length && getenv("GKM_NO_UNIF") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
+                               (packed ? wd_bytes : postab_bytes + (unif ? 0 : wd_bytes));
+        static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
         if (unif) bs = gkm_pick_bitslice(4, L, d);
         bool bperm = false;
         if (!packed && !unif) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
@@ -432,7 +432,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
         A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
-        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.row_wtab = row_wtab;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];

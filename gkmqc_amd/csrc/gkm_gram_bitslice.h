@@ -16,9 +16,9 @@ struct BsArgs {
     const uint32_t *colpk;      /* [seq][pkw][strand] 2-bit packed strands, the two strands interleaved        */
     const uint8_t *wd8;         /* distance-indexed positional weights wd[|n/2 - p|], WD_LDS bytes (ones if unweighted) */
     int rpw, pkw, wd_words;     /* wd_words: dwords of wd8 that hold weights (the kernels copy that many to LDS) */
-    int row_wtab;               /* one-piece variants: byte offset, in the weight area of the dynamic LDS, of the copy of wd8
-                                 * that serves the ROW side; < 0 when every sequence has the same length (the rows then
-                                 * read the column's own table: k_gram_bitslice) */
+    const uint32_t *postab;     /* [seq][ptw] every sequence's weights BY POSITION, L - 1 zero bytes either side (k_build_postab):
+                                 * what the one-piece variants keep in LDS for the column (k_gram_bitslice POSTAB) */
+    int ptw;
     const uint32_t *sb;
     int xw;
     const int *len;

@@ -66,11 +66,14 @@ static_assert(BS_TRIP == 64, "a trip resolves one record per lane");
 /* records the wave-wide hit list holds: >= BS_TRIP + 64, a multiple of 64 (merged LDS stores) */
 constexpr int BS_CAP = BS_TRIP + 64;
 #ifndef GKM_BS_WAVES
-#define GKM_BS_WAVES 6 /* waves per SIMD asked of the compiler for the one-piece-per-lane kernel (<= 80 VGPRs):
-                          config 2 with the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 */
+#define GKM_BS_WAVES 7 /* waves per SIMD asked of the compiler for the same-length kernel, PK = 4 (<= 72 VGPRs).  Round 1, with
+                          the grouped hit ring: 5 -> 96.1 ms, 6 -> 91.8, 7 (spills) -> 97.5 on config 2; rounds 2-4 compiled for 6 and
+                          came out at 69-72 VGPRs, i.e. ran 7.  Round 5's second hit of a visit takes 73 when compiled for 6;
+                          compiled for 7 it fits 72 without scratch: config 2 69.7 -> 68.6 ms, gkmQC's shape 357.3 -> 349.1
+                          (profiles/r5_kernel_ab_hit_path.txt) */
 #endif
 #ifndef GKM_BS_PACKED_WAVES
-#define GKM_BS_PACKED_WAVES 6 /* several-pieces-per-lane kernels: 75-78 VGPRs */
+#define GKM_BS_PACKED_WAVES 6 /* every other variant (ragged lengths): 71-78 VGPRs; compiled for 7 the one-piece ones spill */
 #endif
 #ifndef GKM_TRIP_PRIO
 #define GKM_TRIP_PRIO 3 /* wave priority (s_setprio, 0..3) inside a trip; 0 = as rounds 1-3 */
@@ -85,7 +88,7 @@ constexpr int BS_CAP = BS_TRIP + 64;
  * control flow besides the push.
  */
 template <int W, int L, int D, int PK>
-__global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKED_WAVES : GKM_BS_WAVES) void k_gram_bitslice(const BsArgs A)
+__global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PACKED_WAVES) void k_gram_bitslice(const BsArgs A)
 {
     /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
      *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
@@ -242,22 +245,18 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * are the forward ones mirrored, wt_rc[q] = wt[nB-1-q] (libgkm.c:924): s_wtab[L - 1 + nB - 1 - q].  The windows
          * that wrap around the end of the strand (q = nB .. T - 1: not l-mers, gkm_bitslice.h window_hits) land in the
          * zero bytes behind / before the table: they add 0 to some profile word and need no test.  (A distance-indexed
-         * table cannot do that: |nB/2 - q| of q = nB equals that of q = 0 when nB is even.)  The ROW side reads
-         * wd[|c0 - i0|]: from the right half of the very same table when every sequence of the problem has the same
-         * length (A.row_wtab < 0: no row's distance exceeds the column's nB - 1 - nB/2), else from a copy of wd behind
-         * it, at byte A.row_wtab of the weight area.
+         * table cannot do that: |nB/2 - q| of q = nB equals that of q = 0 when nB is even.)  The ROW side: UNIF reads the
+         * very same table by position (every sequence has the column's length); the other one-piece variants read
+         * wd[|c0 - i0|] from a copy of wd behind it (A.ptw words on).
          * !POSTAB: one distance-indexed table for both sides, as rounds 2-4 had it. */
         const uint32_t ccen = (uint32_t)(nB / 2);
         uint32_t s_rowbase; /* LDS byte offset (from s_dyn) of the row side's wd[0] */
         if (POSTAB) {
-            for (int x = lane; x < T + L - 1; x += 64) {
-                const int p = x - (L - 1), dd = (int)ccen - p;
-                s_wtab[x] = (p >= 0 && p < nB) ? A.wd8[dd < 0 ? -dd : dd] : (uint8_t)0;
-            }
-            if (!UNIF && A.row_wtab >= 0)
-                for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.row_wtab))[x] = ((const uint32_t *)A.wd8)[x];
-            if (UNIF) s_rowbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1);      /* by position */
-            else s_rowbase = (uint32_t)pkw * 8u + (A.row_wtab >= 0 ? (uint32_t)A.row_wtab : (uint32_t)(L - 1) + ccen);
+            /* (built once per sequence by k_build_postab, gkm_context.hip: the wave copies dwords, as it copies the strands) */
+            for (int x = lane; x < A.ptw; x += 64) ((uint32_t *)s_wtab)[x] = A.postab[(size_t)j * A.ptw + x];
+            if (!UNIF)
+                for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = ((const uint32_t *)A.wd8)[x];
+            s_rowbase = (uint32_t)pkw * 8u + (UNIF ? (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u);
         } else {
             for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)s_wtab)[x] = ((const uint32_t *)A.wd8)[x];
             s_rowbase = (uint32_t)pkw * 8u;
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          *   POSTAB:  s_wsign 0 / ~0, s_wbase: the column weight's LDS byte is (q ^ s_wsign) + s_wbase = L-1 + q or
          *            L-1 + nB-1 - q behind the table's start
          *   !POSTAB: s_wbase = [reverse strand and nB even]: wt_rc[q] = wt[nB-1-q] = wd[|q + [nB even] - nB/2|] */
-        uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u;
+        uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u, s_wstep = 1u;
         uint32_t v_rowbase = 0u;
         if (!POSTAB) asm volatile("v_mov_b32 %0, %1" : "=v"(v_rowbase) : "s"(s_rowbase));
 #pragma unroll
@@ -287,7 +286,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
          * lane of packed positions, the column's strands interleaved word by word, (a & const) | b as one
          * v_bitop3_b32, the strand as wave-uniform scalars (the list is emptied between the strands).
          * Same arithmetic as resolve_hit_packed (gkm_bitslice.h), which the CPU tests run against the oracle. */
-        auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b) {
+        auto resolve = [&](uint32_t ms, uint32_t bit, uint32_t pslot4, uint32_t pc0b, uint32_t cont) -> uint32_t {
             const uint32_t lane128 = ms & (63u << META_LANE_SHIFT); /* source lane * 128 */
             const int k = PACKED ? piece_of_bitrow(*(const uint32_t *)((const char *)lmask + (PACKED ? (lane128 >> 5) : 0u)), (int)bit) : 0;
             uint32_t slot4, c0b = 0u; /* row slot * 4; (l-mers of the row) / 2 - p0 + b0*W + 2048 */
@@ -324,16 +323,15 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 const uint8_t *wdb = (const uint8_t *)s_dyn;
                 /* (the table's offset rides in the third operand of the v_sad_u32 that forms the index) */
                 uint32_t wa, wb;
-                if (UNIF) { /* the row l-mer is l-mer pi * capacity + i0 of a sequence as long as the column */
-                    wa = wdb[__umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)segment_capacity(W, L)) + i0 + s_rowbase];
-                    wb = wdb[(q ^ s_wsign) + s_wbase];
-                } else if (POSTAB) {
-                    wa = wdb[__usad(c0b, i0 | 2048u, s_rowbase)];
-                    wb = wdb[(q ^ s_wsign) + s_wbase];
-                } else { /* (the table's offset in a VGPR: |q - centre| + offset would name two SGPRs in one v_sad_u32) */
-                    wa = wdb[__usad(c0b, i0 | 2048u, v_rowbase)];
-                    wb = wdb[__usad(q + s_wbase, ccen, v_rowbase)];
-                }
+                uint32_t ia, ib; /* LDS byte offsets of the two weights */
+                if (UNIF) /* the row l-mer is l-mer pi * capacity + i0 of a sequence as long as the column */
+                    ia = __umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)segment_capacity(W, L)) + i0 + s_rowbase;
+                else if (POSTAB) ia = __usad(c0b, i0 | 2048u, s_rowbase);
+                else ia = __usad(c0b, i0 | 2048u, v_rowbase); /* (offset in a VGPR: |q - centre| + offset would name two SGPRs) */
+                if (POSTAB) ib = (q ^ s_wsign) + s_wbase;
+                else ib = __usad(q + s_wbase, ccen, v_rowbase);
+                wa = wdb[ia];
+                wb = wdb[ib];
                 /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
                 const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
                 const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
@@ -343,7 +341,28 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                  * nothing, wherever m * NSLOT + slot lies in the static LDS (M_FITS).  LDS atomic: ds_add_u32. */
                 if ((POSTAB && M_FITS) || m <= (uint32_t)D)
                     atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+                /* The NEXT position of the same diagonal (row window i0 + 1 against column window q + 1: the same bit of the
+                 * record's next word), when it is a hit too -- 40 % of the visits on gkmQC's shape, because a window pair
+                 * within d mismatches makes its neighbour likely (tools/hits_per_record.py).  It shares the record, the
+                 * piece and both packed windows: two shifts by 2 bits, a second pair of weight bytes (the neighbours of the
+                 * first), a second ds_add. */
+                cont &= (uint32_t)(q + 1u != (uint32_t)T); /* (the column window after the strand's last is its first again) */
+                if (cont) {
+                    uint32_t xr = (ea ^ eb) >> 2;
+                    xr = (xr | (xr >> 1)) & (0x55555555u & ((1u << (2 * L)) - 1u));
+                    const uint32_t m1 = (uint32_t)__builtin_popcount(xr);
+                    uint32_t wa1, wb1;
+                    if (UNIF) wa1 = wdb[ia + 1u];
+                    else if (POSTAB) wa1 = wdb[__usad(c0b, (i0 | 2048u) + 1u, s_rowbase)];
+                    else wa1 = wdb[__usad(c0b, (i0 | 2048u) + 1u, v_rowbase)];
+                    if (POSTAB) wb1 = wdb[ib + s_wstep];
+                    else wb1 = wdb[__usad(q + 1u + s_wbase, ccen, v_rowbase)];
+                    if ((POSTAB && M_FITS) || (m1 <= (uint32_t)D && (int)q + 1 < nB))
+                        atomicAdd((uint32_t *)((char *)accl + (m1 * (uint32_t)(NSLOT * 4) + slot4)), wa1 * wb1);
+                }
+                return cont; /* (the visit took the pair) */
             }
+            return 0u;
         };
 
         /* one trip over the `c` records on top of the list (PARTIAL: c < BS_TRIP, the last trip of a column) */
@@ -380,7 +399,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
             for (int g = 0; g < BS_GRP; g++) total = popc_add(h[g], total);
             uint32_t sel = first >> 5;
             const uint32_t bit = first & 31u;
-#if defined(GKM_PROBE_VALU_F) || defined(GKM_PROBE_VALU_H) || defined(GKM_PROBE_LDS) || defined(GKM_PROBE_LAT)
+#if defined(GKM_PROBE_VALU_F) || defined(GKM_PROBE_VALU_H) || defined(GKM_PROBE_LDS) || defined(GKM_PROBE_LDS64) || defined(GKM_PROBE_LAT)
             /* SENSITIVITY PROBES (experiments only, results unchanged): what one more full-rate / half-rate VALU
              * instruction, one more LDS operation, one more dependent LDS round trip per trip costs */
             {
@@ -396,6 +415,14 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
 #ifdef GKM_PROBE_LDS
 #pragma unroll
                 for (int z = 0; z < GKM_PROBE_LDS; z++) asm volatile("ds_add_u32 %0, %1" : : "v"(lane4), "v"(0u) : "memory");
+#endif
+#ifdef GKM_PROBE_LDS64 /* the same with 8 bytes per lane: is an LDS operation's cost its instruction or its bytes? */
+                {
+                    const unsigned long long z64 = 0ull;
+                    const uint32_t lane8 = lane4 + lane4;
+#pragma unroll
+                    for (int z = 0; z < GKM_PROBE_LDS64; z++) asm volatile("ds_add_u64 %0, %1" : : "v"(lane8), "v"(z64) : "memory");
+                }
 #endif
 #ifdef GKM_PROBE_LAT
 #pragma unroll
@@ -416,7 +443,17 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                 pc0b = both >> 16;
             }
             /* every record of a full trip holds a hit (only records with one are pushed or pushed again): no test */
-            if (!PARTIAL || total) resolve(ms, bit, pslot4, pc0b);
+            uint32_t cont = 0u;
+            {
+                /* is the same bit of the record's NEXT word set (the record still sits in the list where it was read)?
+                 * Not for the group's last word (sel = 4: what follows is the origin word). */
+                const uint32_t nxt = *(const uint32_t *)(at + ((sel + 1u) << 9));
+                static_assert(BS_CAP * 4 == 512, "word g of a record is g * 512 bytes on");
+                cont = ((nxt >> bit) & 1u) & ~(first >> 7);
+            }
+            uint32_t took = 0u; /* 1: the visit resolved the hit's neighbour on the diagonal too */
+            if (!PARTIAL || total) took = resolve(ms, bit, pslot4, pc0b, cont);
+            total -= took;
             s_n -= c;
             const unsigned long long more = __ballot(total > 1u);
             if (more) {
@@ -428,6 +465,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
                     for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(to + g * BS_CAP * 4) = h[g];
                     *(uint32_t *)(to + BS_GRP * BS_CAP * 4) = meta;
                     atomicXor((uint32_t *)(to + sel * (uint32_t)(BS_CAP * 4)), 1u << bit); /* ds_xor_b32: that hit is done */
+                    if (took) atomicXor((uint32_t *)(to + (sel + 1u) * (uint32_t)(BS_CAP * 4)), 1u << bit);
                 }
                 s_n += (int)__popcll(more);
             }
@@ -453,6 +491,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : (PK == 1 || PK == 2) ? GKM_BS_PACKE
         for (int strand = 0; strand < 2; strand++) {
             s_strand4 = (uint32_t)strand * 4u + (COL_BASE_FOLDS ? (uint32_t)(STATIC_WORDS * 4) : 0u);
             s_wsign = strand ? ~0u : 0u;
+            s_wstep = strand ? ~0u : 1u; /* POSTAB: the next window's weight byte is the next / the previous one */
             if (POSTAB) s_wbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u); /* ~q = -q - 1 */
             else s_wbase = (strand && !(nB & 1)) ? 1u : 0u;
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with

@@ -103,6 +103,10 @@ struct gkmhip_ctx {
                                * (k_pack_strands; gkm_bitslice.h pk_word): the hit path's column side */
     int pkw = 0;
     bool have_colpk = false;
+    DevBuf<uint32_t> postab;  /* [seq][ptw] positional weights with zero guard bands (k_build_postab): the hit path's column
+                               * weights in the one-piece variants */
+    int ptw = 0;
+    bool have_postab = false;
     uint32_t lm_stride = 0;
     int sb_xw = 0, sb_W = 0;
     bool have_lmers = false, have_sb = false;
@@ -141,6 +145,7 @@ constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| 
 /* per-sequence device tables (gkm_context.hip): built by gkmhip_set_sequences, complete before any launch */
 int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream);
 int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream);
+int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream);
 int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream);
 bool bitslice_serves(const gkmhip_ctx *ctx); /* which kernel this context's launches take (gkm_gram.hip) */
 

@@ -340,7 +340,7 @@ def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
     z = helpers.synthetic_expected()
     seqs = helpers.synth_codes(192, 192, 300)
     il = np.tril_indices(len(seqs))
-    for forced, name in ((None, "k_gram_bitslice"), ("1", "k_gram_bitslice<packed>"), ("128", "k_gram_bitslice<packed,128>")):
+    for forced, name in ((None, "k_gram_bitslice<same length>"), ("1", "k_gram_bitslice<packed>"), ("128", "k_gram_bitslice<packed,128>")):
         if forced:
             monkeypatch.setenv("GKM_FORCE_PACKED", forced)
         res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
@@ -350,21 +350,19 @@ def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
 
 
 def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
-    """One piece per lane: the trip reads the source lane's piece entry from a 512-byte LDS table, or from that
-    lane's registers (ds_bpermute) where the table would cost an LDS allocation granule (long sequences).  Both
-    variants, forced either way, on 300-bp rows (one lane each) and 600-bp rows (two lanes each)."""
+    """One piece per lane, three ways for a trip to learn the source lane's row slot and weight offset: from the record's
+    origin word itself where every sequence has the same length (the default there, round 5: no table, no permute), from a
+    512-byte LDS table, or from the source lane's registers (ds_bpermute) where that table would cost an LDS allocation
+    granule.  The latter two serve ragged one-piece data; here they are forced (GKM_NO_UNIF) onto 300-bp rows (one lane
+    each) and 600-bp rows (two lanes each) so that all three see the same fixtures, bit for bit."""
     z = helpers.synthetic_expected()
     seqs = helpers.synth_codes(192, 192, 300)
     il = np.tril_indices(len(seqs))
-    assert dev.gram_matrix(seqs, 4, 11, 7, 3, kernel=dev.KERNEL_BITSLICE)["kernel"] == "k_gram_bitslice"
     long_rows = helpers.synth_codes(70, 70, 600)
     want = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
-    auto = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
-    assert auto["kernel"] == "k_gram_bitslice<bperm>"
     il2 = np.tril_indices(len(long_rows))
-    assert (auto["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
-    for forced, name in (("1", "k_gram_bitslice<bperm>"), ("0", "k_gram_bitslice")):
-        monkeypatch.setenv("GKM_FORCE_BPERM", forced)
+
+    def check(name):
         res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
         assert res["kernel"] == name
         assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
@@ -372,6 +370,22 @@ def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
         assert res["kernel"] == name
         assert (res["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
         assert (res["K"].cpu().numpy() == want["K"].cpu().numpy()).all()
+
+    check("k_gram_bitslice<same length>")
+    monkeypatch.setenv("GKM_NO_UNIF", "1")
+    assert dev.gram_matrix(seqs, 4, 11, 7, 3, kernel=dev.KERNEL_BITSLICE)["kernel"] in ("k_gram_bitslice", "k_gram_bitslice<bperm>")
+    for forced, name in (("1", "k_gram_bitslice<bperm>"), ("0", "k_gram_bitslice")):
+        monkeypatch.setenv("GKM_FORCE_BPERM", forced)
+        check(name)
+    monkeypatch.delenv("GKM_FORCE_BPERM")
+    monkeypatch.delenv("GKM_NO_UNIF")
+    # ragged lengths that still take one lane per row: the table / permute variants are what `auto` runs there
+    ragged = helpers.synth_codes(100, 100, 300, (200, 318))
+    r = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    w = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    il3 = np.tril_indices(len(ragged))
+    assert r["kernel"] in ("k_gram_bitslice", "k_gram_bitslice<bperm>")
+    assert (r["P"].cpu().numpy()[il3] == w["P"].cpu().numpy()[il3]).all() and (r["K"].cpu().numpy() == w["K"].cpu().numpy()).all()
 
 
 def test_reused_context_with_longer_second_subset(dev):

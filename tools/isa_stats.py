@@ -13,7 +13,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
-HOT = ["10,11,3,0", "10,10,3,3", "10,12,4,1"]   # config 2, gkmQC's own shape (600 bp), config 5 (ragged)
+HOT = ["10,11,3,4", "10,10,3,4", "10,12,4,1"]   # config 2, gkmQC's own shape (600 bp), config 5 (ragged)
 
 
 def unbundle(obj):

@@ -9,7 +9,7 @@ v_cndmask, SDWA / DPP forms, packed 16-bit operations, and any instruction with 
 VALU instruction with those two rates, and splits the kernel into the counting loop (everything outside the trips,
 per shift) and one trip (between the ring read that precedes the first v_ffbl_b32 and the ds_xor_b32 that ends it).
 
-    python3 tools/issue_model.py [--object gkmqc_amd/csrc/build/gkm_gram_bitslice.o] [--kernel 10,11,3,0] [--shifts-per-block 4]
+    python3 tools/issue_model.py [--object gkmqc_amd/csrc/build/gkm_gram_bitslice.o] [--kernel 10,11,3,4] [--shifts-per-block 4]
         [--waves N --T len --trips N --ms measured]
 
 With --waves/--T/--trips it predicts the kernel time as (shifts x counting cost + trips x trip cost) / (1024 SIMDs x
@@ -35,6 +35,13 @@ FULL = {"v_xor_b32", "v_and_b32", "v_or_b32", "v_add_u32", "v_sub_u32", "v_subre
 # v_not, v_mov, v_lshrrev: 2.07-2.11; v_bitop3 with two VGPR sources 2.27) and 3.8 for a half-rate opcode among full-rate
 # ones ("four alternating with full-rate ones 3.8 each").  The model is good to about +-5 %.
 C_FULL, C_SGPR, C_HALF = 2.1, 2.1, 3.8
+# Round 5 (sensitivity probes, profiles/r5_trip_sensitivity.txt: builds with 16 more VALU instructions / 4 more LDS
+# operations per trip): inside a trip one more VALU instruction costs 1.9 (full-rate) to 2.1 ("half-rate") SIMD-cycles --
+# the second pass of a half-rate opcode hides among the trip's waits -- and one more LDS instruction costs 5.8: THREE VALU
+# instructions.  The VALU-only prices above therefore UNDER-price a trip (12-15 LDS instructions) and over-price its
+# half-rate opcodes; `cycles_all` below is the round-5 price: every VALU instruction of a trip 2.0, of the counting loop as
+# above, every LDS instruction 5.8, the vector-memory gather ~14 (what one more gather cost the first round-5 hit path).
+C_TRIP_VALU, C_LDS, C_VMEM = 2.0, 5.8, 14.0
 
 
 def disassemble(obj, kernel):
@@ -135,10 +142,14 @@ def analyse(obj, kernel, du):
         nshift, rest = 2 * du, [x for i, x in enumerate(lines) if i not in in_trip]
     tf, (ts, th), tc = cost(trip)
     rf, (rs, rh), rc = cost(rest)
+    t_lds, t_vmem = sum(x.startswith("ds_") for x in trip), sum(x.startswith(("global_", "buffer_")) for x in trip)
+    r_lds = sum(x.startswith("ds_") for x in rest) / nshift
     return {"symbol": sym, "instructions": len(lines), "trip_copies": len(copies),
-            "trip": {"full_rate": tf, "sgpr_operand": ts, "half_rate": th, "cycles": tc, "lds": sum(x.startswith("ds_") for x in trip),
-                     "vmem": sum(x.startswith(("global_", "buffer_")) for x in trip), "salu": sum(x.startswith("s_") for x in trip)},
+            "trip": {"full_rate": tf, "sgpr_operand": ts, "half_rate": th, "cycles": tc, "lds": t_lds,
+                     "vmem": t_vmem, "salu": sum(x.startswith("s_") for x in trip),
+                     "cycles_all": (tf + ts + th) * C_TRIP_VALU + t_lds * C_LDS + t_vmem * C_VMEM},
             "per_shift": {"full_rate": rf / nshift, "sgpr_operand": rs / nshift, "half_rate": rh / nshift, "cycles": rc / nshift,
+                          "lds": r_lds, "cycles_all": rc / nshift + r_lds * C_LDS,
                           "note": "the loop over blocks of %d shifts, trips taken out, / %d" % (nshift, nshift)}}
 
 
@@ -153,15 +164,19 @@ def from_pmc(model, pmc, mean_T, kernel_ns):
     issue = shifts * model["per_shift"]["cycles"] + trips * model["trip"]["cycles"]
     clock = p["GRBM_GUI_ACTIVE"] / 8.0 / (kernel_ns * 1e-9)           # GRBM_GUI_ACTIVE is summed over the 8 XCDs
     have = kernel_ns * 1e-9 * clock * 1024                              # SIMD-cycles of the launch
+    issue_all = shifts * model["per_shift"]["cycles_all"] + trips * model["trip"]["cycles_all"]
     return {"shifts": shifts, "trips": trips, "valu_in_trips": trips * per_trip / p["SQ_INSTS_VALU"],
             "issue_cycles": issue, "simd_cycles": have, "clock_GHz": clock / 1e9, "issue_frac": issue / have,
-            "issue_cycles_in_trips": trips * model["trip"]["cycles"] / issue}
+            "issue_cycles_in_trips": trips * model["trip"]["cycles"] / issue,
+            # round 5's prices (LDS instructions included): what share of the launch's SIMD-cycles they account for
+            "issue_cycles_all": issue_all, "issue_frac_all": issue_all / have,
+            "issue_cycles_all_in_trips": trips * model["trip"]["cycles_all"] / issue_all}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--object", default=os.path.join(ROOT, "gkmqc_amd", "csrc", "build", "gkm_gram_bitslice.o"))
-    ap.add_argument("--kernel", default="10,11,3,0", help="W,L,D,PK of the instantiation")
+    ap.add_argument("--kernel", default="10,11,3,4", help="W,L,D,PK of the instantiation")
     ap.add_argument("--shifts-per-block", type=int, default=4, help="GKM_BS_DU")
     ap.add_argument("--waves", type=float, default=None)
     ap.add_argument("--T", type=float, default=None, help="(mean) column length: a wave sweeps 2 T shifts")
@@ -178,9 +193,10 @@ def main():
         import bench
         out = {"what": "tools/issue_model.py: VALU issue cycles of the hot kernel priced with the two issue rates of "
                        "gfx950 (profiles/r3_valu_ops.txt) against the SIMD-cycles its launch had",
-               "cycles_full_rate": C_FULL, "cycles_sgpr_operand": C_SGPR, "cycles_half_rate": C_HALF, "kernel_source_sha256": bench.kernel_source_hash(),
+               "cycles_full_rate": C_FULL, "cycles_sgpr_operand": C_SGPR, "cycles_half_rate": C_HALF,
+               "cycles_trip_valu": C_TRIP_VALU, "cycles_lds": C_LDS, "cycles_vmem": C_VMEM, "kernel_source_sha256": bench.kernel_source_hash(),
                "workloads": {}}
-        for wl, kern, T in (("c2", [10, 11, 3, 0], 300.0), ("peaks", [10, 10, 3, 3], 600.0), ("c5", [10, 12, 4, 1], None)):
+        for wl, kern, T in (("c2", [10, 11, 3, 4], 300.0), ("peaks", [10, 10, 3, 4], 600.0), ("c5", [10, 12, 4, 1], None)):
             pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (a.round, wl))
             cs = os.path.join(ROOT, "profiles", "%s_kernel_stats_%s.csv" % (a.round, wl))
             if not (os.path.exists(pj) and os.path.exists(cs)):
@@ -203,11 +219,11 @@ def main():
             d = m["measured"]
             print("%-6s trip %d F + %d S + %d H = %.0f cycles, shift %.0f F + %.0f S + %.0f H = %.1f cycles; %.3g shifts, %.3g trips "
                   "(%.0f %% of the VALU instructions, %.0f %% of the issue cycles) -> issue cycles / SIMD-cycles = %.3f at %.2f GHz, "
-                  "kernel %.1f ms"
+                  "kernel %.1f ms; with LDS instructions priced (round 5): %.3f, trips %.0f %% of it"
                   % (wl, m["trip"]["full_rate"], m["trip"]["sgpr_operand"], m["trip"]["half_rate"], m["trip"]["cycles"],
                      m["per_shift"]["full_rate"], m["per_shift"]["sgpr_operand"], m["per_shift"]["half_rate"], m["per_shift"]["cycles"],
                      d["shifts"], d["trips"], 100 * d["valu_in_trips"], 100 * d["issue_cycles_in_trips"], d["issue_frac"],
-                     d["clock_GHz"], ns / 1e6))
+                     d["clock_GHz"], ns / 1e6, d["issue_frac_all"], 100 * d["issue_cycles_all_in_trips"]))
         json.dump(out, open(os.path.join(ROOT, "profiles", "%s_issue_model.json" % a.round), "w"), indent=1, sort_keys=True)
         return 0
     m = analyse(a.object, [int(x) for x in a.kernel.split(",")], a.shifts_per_block)
