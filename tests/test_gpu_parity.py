@@ -380,7 +380,7 @@ def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
     monkeypatch.delenv("GKM_FORCE_BPERM")
     monkeypatch.delenv("GKM_NO_UNIF")
     # ragged lengths that still take one lane per row: the table / permute variants are what `auto` runs there
-    ragged = helpers.synth_codes(100, 100, 300, (200, 318))
+    ragged = helpers.synth_codes(100, 100, 300, (305, 320))
     r = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
     w = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
     il3 = np.tril_indices(len(ragged))
