@@ -432,7 +432,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
         A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
-        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
         uint32_t s_rowbase; /* LDS byte offset (from s_dyn) of the row side's wd[0] */
         if (POSTAB) {
             /* (built once per sequence by k_build_postab, gkm_context.hip: the wave copies dwords, as it copies the strands) */
-            for (int x = lane; x < A.ptw; x += 64) ((uint32_t *)s_wtab)[x] = A.postab[(size_t)j * A.ptw + x];
+            for (int x = lane; x < A.ptw; x += 64) ((uint32_t *)s_wtab)[x] = A.postab[(size_t)j * A.ptw_stride + x];
             if (!UNIF)
                 for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = ((const uint32_t *)A.wd8)[x];
             s_rowbase = (uint32_t)pkw * 8u + (UNIF ? (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u);
