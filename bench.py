@@ -414,6 +414,9 @@ def side_workload(name, dev, steps=3):
                 "steps": steps, "ms_per_step": wall * 1e3, "pairs_per_s": (n * (n - 1) / 2) / wall, "parity": parity,
                 "kernel": ctx.last_kernel_name(), "kernel_ms": kern_s * 1e3, "comparisons_per_s": comparisons / kern_s,
                 "frac": (insts * 64 / kern_s / 1e9 / PEAK_INT32_GOPS) if insts else None, "pmc_source": src,
+                # what `frac` hides: a kernel that needs fewer instructions for the same comparisons is the faster one
+                "executed_insts_per_comparison": (insts * 64 / comparisons) if insts else None,
+                "comparisons_per_launch": comparisons,
                 "issue_cycles_over_simd_cycles": (issue_model(name) or {}).get("issue_cycles_over_simd_cycles")}
     finally:
         ctx.close()

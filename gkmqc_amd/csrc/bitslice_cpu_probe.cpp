@@ -252,3 +252,16 @@ extern "C" void shardprobe_packed_gather_offsets(int n, int world, int chunks, i
 }
 
 extern "C" int shardprobe_auto_chunks(int n, int world) { return gkmshard::auto_chunks(n, world); }
+
+/* work items (tile, column) of a triangular launch over `rows` packed with / without closing tiles at jumps in the row
+ * list (gkm_pack.h pack_rows split_jump), and the number of tiles; every row must have found a slot */
+extern "C" long long packprobe_triangle_items(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows,
+                                              int split_jump, int *ntiles_out)
+{
+    const gkmpack::Packing P = gkmpack::pack_rows(rows, nwin, nrows, W, L, max_rows, split_jump);
+    long placed = 0;
+    for (int t = 0; t < P.ntiles; t++) placed += P.tile_nrows[(size_t)t];
+    if (placed != nrows) return -1;
+    if (ntiles_out) *ntiles_out = P.ntiles;
+    return gkmpack::triangle_items(P);
+}

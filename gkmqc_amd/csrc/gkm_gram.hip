@@ -241,10 +241,18 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
         /* At most 64 rows per tile unless that leaves lanes empty (rows shorter than half a lane): the
          * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
-        gkmpack::Packing pk = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, 64);
+        /* (a jump in the row list -- a multi-GPU rank's two folded row blocks -- closes the tile where that means fewer
+         * work items: gkm_pack.h) */
+        auto pack = [&](int max_rows) {
+            gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows);
+            if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
+            gkmpack::Packing b = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, gkmpack::LANES);
+            return gkmpack::triangle_items(b) < gkmpack::triangle_items(a) ? b : a;
+        };
+        gkmpack::Packing pk = pack(64);
         int slots = 64;
         {
-            gkmpack::Packing wide = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, gkmpack::MAX_ROWS);
+            gkmpack::Packing wide = pack(gkmpack::MAX_ROWS);
             if (getenv("GKM_FORCE_PACKED") ? !strcmp(getenv("GKM_FORCE_PACKED"), "128")
                                            : (double)pk.ntiles > 1.04 * (double)wide.ntiles) {
                 pk = std::move(wide);

@@ -501,7 +501,9 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             for (int d0 = 0; d0 < T; d0 += BS_DU) {
                 /* (copying the words to VGPRs once instead of using them as SGPR operands was measured
                  * slower: 119-129 ms against 111.6 ms on config 2; requesting the next block's words one
-                 * block ahead changes nothing: 92.3 against 92.4 ms) */
+                 * block ahead changes nothing: 92.3 against 92.4 ms; round 5: touching the cache line 48 words ahead
+                 * with a throw-away scalar load changes nothing either, not even in the small launches of an 8-way
+                 * split where 1 wave in 10-20 is the first to read its column -- profiles/r5_small_launch_probe.txt) */
                 /* the strand's window-validity plane (third SB plane) is not streamed: wrapped
                  * windows are rejected when a hit is resolved (gkm_bitslice.h window_hits) */
                 uint32_t bh[BS_DU + W - 1], bl[BS_DU + W - 1];

@@ -48,8 +48,14 @@ struct Packing {
 
 /* rows: ascending sequence indices; nwin[i]: l-mer windows of rows[i] (>= 1).
  * Greedy first-fit in row order (the order matters: a tile only visits columns j <= its largest
- * row, so tiles should hold neighbouring rows). */
-inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows = MAX_ROWS)
+ * row, so tiles should hold neighbouring rows).
+ * split_jump: a JUMP of at least that many rows in the list (the folded row blocks of a multi-GPU rank: rows 0..624, then
+ * 9375..9999) closes the current tile.  Every work item of a tile is 64 lanes x one column for ALL columns up to the
+ * tile's largest row, so low rows that share a tile with high ones ride along through thousands of columns they do not
+ * need: rank 0 of an 8-way split of config 2 ran 109 660 work items instead of 100 760 (round 5,
+ * profiles/r5_small_launch_blocks.txt).  Whether splitting pays depends on the list (it can also cost a tile); the caller
+ * packs both ways and keeps the one with fewer work items (triangle_items). */
+inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows = MAX_ROWS, int split_jump = 0)
 {
     Packing P;
     P.W = W;
@@ -70,6 +76,8 @@ inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int
         }
     };
     for (int i = 0; i < nrows; i++) {
+        /* split_jump > 0: a jump of at least that many rows in the list closes the tile (see the function's header) */
+        if (split_jump > 0 && i > 0 && tile_rows > 0 && rows[i] - rows[i - 1] >= split_jump) close_tile();
         for (int attempt = 0; attempt < 2; attempt++) {
             if (tile_rows >= max_rows) close_tile();
             open_tile_storage();
@@ -130,6 +138,14 @@ inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int
     }
     P.lanes_used = lanes;
     return P;
+}
+
+/* work items of a launch that visits, for every tile, the columns 0 .. its largest row (the triangle) */
+inline long long triangle_items(const Packing &P)
+{
+    long long items = 0;
+    for (int t = 0; t < P.ntiles; t++) items += (long long)P.tile_amax[(size_t)t] + 1;
+    return items;
 }
 
 /* relative cost of running the kernel with this packing: lanes x (per-word cost x W + fixed

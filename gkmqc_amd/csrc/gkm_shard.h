@@ -7,9 +7,9 @@
  * Row a of the lower triangle costs ~ (a + 1) column sequences, so equal row blocks are unbalanced.
  * Folded pairing: the rows are cut into 2 G contiguous blocks of `blk` rows, rank g owns blocks g and
  * 2G-1-g: equal row counts (an all-gather needs equal send counts) and equal area within ~1 %.
- * A rank's rows are dealt to `chunks` sub-lists in groups of 64 consecutive rows (one tile of the
- * Gram kernel), round robin, so that the all-gather of chunk c can overlap the kernel of chunk c+1
- * and every chunk carries the same mix of cheap and expensive rows.
+ * The rows of each of a rank's two blocks are dealt to `chunks` sub-lists in groups of 64 consecutive rows (one tile of
+ * the Gram kernel; a group never reaches across the two blocks), round robin, so that the all-gather of chunk c can
+ * overlap the kernel of chunk c+1 and every chunk carries the same mix of cheap and expensive rows.
  *
  * PACKED slabs (round 4).  Only the cells j <= a of row a are ever computed or read (the consumer is the
  * un-permute + normalise pass, k_assemble_normalize), so a chunk's slab holds row a as a + 1 doubles, the rows of
@@ -47,12 +47,27 @@ inline std::vector<int> folded_rows(int n, int world, int rank)
     return rows;
 }
 
-/* rows per chunk slab: the largest chunk of a full slab */
+/* chunk of each position of a row list made of blocks of `lens` rows: 64-row groups dealt round robin, a group never
+ * reaching across two blocks.  (Round 5: a group that held the last 49 rows of a rank's low block and the first 15 of its
+ * high block became ONE tile of the Gram kernel, and the 49 low rows rode along through the thousands of columns only the
+ * high rows need: 8.8 % more work items for rank 0 of an 8-way split of config 2, profiles/r5_small_launch_blocks.txt.) */
+inline std::vector<int> chunk_of_position(const std::vector<int> &lens, int chunks)
+{
+    std::vector<int> which;
+    int g0 = 0;
+    for (int ln : lens) {
+        for (int i = 0; i < ln; i++) which.push_back((g0 + i / CHUNK_GROUP) % chunks);
+        g0 += (ln + CHUNK_GROUP - 1) / CHUNK_GROUP;
+    }
+    return which;
+}
+
+/* rows per chunk slab: the largest chunk of a full slab (two whole blocks) */
 inline int chunk_rows(int n, int world, int chunks)
 {
-    const int per = slab_rows(n, world);
+    const int blk = block_rows(n, world);
     std::vector<int> cnt((size_t)chunks, 0);
-    for (int i = 0; i < per; i++) cnt[(size_t)((i / CHUNK_GROUP) % chunks)]++;
+    for (int c : chunk_of_position({blk, blk}, chunks)) cnt[(size_t)c]++;
     int pc = 0;
     for (int c : cnt) pc = c > pc ? c : pc;
     return pc;
@@ -61,8 +76,16 @@ inline int chunk_rows(int n, int world, int chunks)
 inline std::vector<std::vector<int>> chunked_layout(int n, int world, int rank, int chunks)
 {
     const std::vector<int> rows = folded_rows(n, world, rank);
+    const int blk = block_rows(n, world), hi = 2 * world - 1 - rank;
+    auto len_of = [&](int b) {
+        const long lo = (long)b * blk, up = (long)(b + 1) * blk;
+        return (int)((up < n ? up : n) - (lo < n ? lo : n));
+    };
+    std::vector<int> lens = {len_of(rank)};
+    if (hi != rank) lens.push_back(len_of(hi));
+    const std::vector<int> which = chunk_of_position(lens, chunks);
     std::vector<std::vector<int>> parts((size_t)chunks);
-    for (size_t i = 0; i < rows.size(); i++) parts[(i / CHUNK_GROUP) % (size_t)chunks].push_back(rows[i]);
+    for (size_t i = 0; i < rows.size(); i++) parts[(size_t)which[i]].push_back(rows[i]);
     return parts;
 }
 

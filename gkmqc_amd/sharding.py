@@ -46,23 +46,37 @@ def gather_index(n, world_size):
 CHUNK_GROUP = 64    # rows dealt to a chunk at a time: one 64-lane tile of the Gram kernel for fixed-length data
 
 
-def _chunk_of_position(count, chunks):
-    """Chunk of each of `count` consecutive positions of a rank's row list."""
-    return (np.arange(count) // CHUNK_GROUP) % chunks
+def _chunk_of_position(block_lens, chunks):
+    """Chunk of each position of a rank's row list, which is made of blocks of `block_lens` rows: 64-row groups dealt
+    round robin, a group never reaching across two blocks.  (Round 5: a group that held the last 49 rows of the rank's low
+    block and the first 15 of its high block became ONE tile of the Gram kernel, and the 49 low rows rode along through
+    the thousands of columns only the high rows need -- 8.8 % more work items for rank 0 of an 8-way split of config 2.)"""
+    which, g0 = [], 0
+    for ln in block_lens:
+        which.append((g0 + np.arange(ln) // CHUNK_GROUP) % chunks)
+        g0 += -(-ln // CHUNK_GROUP)
+    return np.concatenate(which) if which else np.zeros(0, dtype=np.int64)
+
+
+def _block_lens(n, world_size, rank):
+    g2 = 2 * world_size
+    blk = -(-n // g2)
+    hi_blk = g2 - 1 - rank
+    return [max(0, min((rank + 1) * blk, n) - rank * blk), max(0, min((hi_blk + 1) * blk, n) - min(hi_blk * blk, n))]
 
 
 def chunked_layout(n, world_size, rank, chunks):
-    """Split this rank's rows into `chunks` sub-lists.  The rank's rows are dealt to the chunks in
-    groups of CHUNK_GROUP CONSECUTIVE rows, round robin: every chunk carries the same mix of cheap
+    """Split this rank's rows into `chunks` sub-lists.  The rows of each of the rank's two blocks are dealt to the chunks
+    in groups of CHUNK_GROUP CONSECUTIVE rows, round robin: every chunk carries the same mix of cheap
     and expensive rows, and the rows a tile of the kernel holds stay neighbours (a tile visits all
     columns up to its largest row, so a tile of rows 4 apart would do 3.8 % more work on the
     headline problem).  The Gram kernel runs once per chunk and each chunk's slab is all-gathered on
     its own, which lets the collective of chunk c overlap the kernel of chunk c+1.
     Returns (list of ascending row arrays, rows_per_chunk = slab height of every chunk)."""
     rows, _ = folded_rows(n, world_size, rank)
-    per = slab_rows(n, world_size)
-    which = _chunk_of_position(len(rows), chunks)
-    pc = int(np.bincount(_chunk_of_position(per, chunks), minlength=chunks).max())
+    blk = -(-n // (2 * world_size))
+    which = _chunk_of_position(_block_lens(n, world_size, rank), chunks)
+    pc = int(np.bincount(_chunk_of_position([blk, blk], chunks), minlength=chunks).max())
     return [rows[which == c] for c in range(chunks)], pc
 
 

@@ -107,3 +107,33 @@ def test_packed_lanes_match_oracle(libs, W, L, d):
     # the packing is dense: lanes used stay close to the information-theoretic minimum
     need = sum(-(-len(s) // W) for s in seqs) / 32.0
     assert used.value <= 1.25 * need + 2
+
+
+def test_tiles_are_closed_at_jumps_in_the_row_list_where_that_saves_work_items(libs):
+    """A multi-GPU rank's rows are two folded blocks (gkm_shard.h): rows 0..624 and 9375..9999 for rank 0 of an 8-way split
+    of 10 000.  Packed in one go, the 49 low rows left over after nine full tiles share a tile with 15 high rows and ride
+    along through 8 765 columns they do not need (measured: 109 660 work items instead of 100 760,
+    profiles/r5_small_launch_blocks.txt); pack_rows(split_jump=64) closes the tile at the jump.  Adjacent blocks (rank 7)
+    have no jump and must pack as before; a list with small regular gaps (every third row) must not be split."""
+    import ctypes
+    probe = libs[1] if isinstance(libs, tuple) else libs
+    fn = probe.packprobe_triangle_items
+    fn.restype = ctypes.c_longlong
+
+    def items(rows, split):
+        rows = np.ascontiguousarray(rows, dtype=np.int32)
+        nwin = np.full(len(rows), 290, dtype=np.int32)
+        nt = ctypes.c_int(0)
+        got = fn(rows.ctypes.data_as(ctypes.c_void_p), nwin.ctypes.data_as(ctypes.c_void_p), len(rows), 10, 11, 64, split,
+                 ctypes.byref(nt))
+        assert got > 0
+        return got, nt.value
+
+    rank0 = np.concatenate([np.arange(0, 625), np.arange(9375, 10000)])
+    mixed, t0 = items(rank0, 0)
+    split, t1 = items(rank0, 64)
+    assert mixed == 109660 and split == 100760 and t1 == t0     # the same 20 tiles, 8.1 % fewer work items
+    rank7 = np.arange(4375, 5625)
+    assert items(rank7, 0) == items(rank7, 64)
+    thirds = np.arange(0, 3000, 3)
+    assert items(thirds, 0) == items(thirds, 64)
