@@ -129,13 +129,13 @@ inline int64_t packed_chunk_elems(int n, int world, int chunks)
     return pe;
 }
 
-/* Chunks per rank when the caller does not say.  A chunk more costs a launch more -- ramp and drain, ~0.7 ms beside a
- * kernel of 75 ms / ranks -- and hides 1 / chunks more of the transfer (n = 10 000: ~0.36 GB received per rank, 1-5 ms
- * over xGMI): chunks ~ sqrt(transfer / 0.7 ms) says 2, at most 3, for 2 to 8 ranks.  Second concern: 64-row groups
- * dealt round robin leave some chunk with one expensive group more than the others, and every chunk slab is padded to
- * the largest (21 % of the bytes with 4 chunks at n = 10 000 on 8 ranks, 2 % with 2).  So: 2, unless 3 pads at least
- * 3 % less, else 4 likewise.  (Unmeasured on hardware: no round has had more than one GPU; GKM_BENCH_CHUNKS and the
- * `chunks` argument override.) */
+/* Chunks per rank when the caller does not say.  A chunk more costs a launch more -- measured in round 5 with one rank
+ * alone on a GPU (tools/rank_alone.py, 8-way split of n = 10 000): 10.58 / 10.54 / 10.85 / 11.05 ms per rank with 1 / 2 /
+ * 3 / 4 chunks, i.e. ~0.25 ms per further launch beside a kernel of ~9 ms -- and hides 1 / chunks more of the transfer
+ * (~0.36 GB received per rank, 1-5 ms over xGMI): 2, at most 3, for 2 to 8 ranks.  Second concern: 64-row groups dealt
+ * round robin leave some chunk with one expensive group more than the others, and every chunk slab is padded to the
+ * largest (21 % of the bytes with 4 chunks at n = 10 000 on 8 ranks, 2 % with 2).  So: 2, unless 3 pads at least 3 % less,
+ * else 4 likewise.  (GKM_BENCH_CHUNKS and the `chunks` argument override.) */
 inline int auto_chunks(int n, int world)
 {
     if (world <= 1) return 1;
