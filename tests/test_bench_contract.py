@@ -45,8 +45,16 @@ def test_one_json_line_with_roofline_end_to_end_and_cpu_baseline(built, forced_d
     assert rf["algorithmic_frac"] == pytest.approx(rf["algorithmic_Gops"] / rf["peak"])
     cb = d["cpu_baseline"]
     assert cb["kind"] in ("reference", "port") and cb["value"] > 0 and cb["cores"] >= 1 and cb["sample"]
+    if not forced_dist:
+        # the dominant kernel and the rest of a step are parts of the TIMED steps (gkmhip_kernel_timeline + events around
+        # every step): a line whose kernel is longer than its step is not self-consistent
+        assert "timed steps" in rf["kernel_ms_source"] and rf["small_kernels_ms"] >= 0
+        assert rf["kernel_ms"] + rf["small_kernels_ms"] == pytest.approx(rf["step_span_ms"]) and rf["step_span_ms"] <= d["ms_per_step"] * 1.001
     e2e = d["end_to_end"]
     assert e2e["boundary_ms"] > 0 and e2e["pipeline_ms"] > 0 and 0.0 <= e2e["pipeline_auc"] <= 1.0
+    # the reference caller's own geometry: a FRESH zeroed 15 000 x 15 000 matrix per call (scripts/gkmsvm.py:75-77)
+    assert e2e["boundary_fresh_matrix_ms"] > 0 and e2e["boundary_fresh_matrix_rows"] == 15000
+    assert e2e["boundary_fresh_matrix_untouched_outside"] is True and e2e["boundary_parity"]["fixture"] is None
     assert "workload" in d["config"] and "model" not in d["config"]
     # the parity gate is part of every line; a custom size has no reference digest and says so (never a guess)
     assert d["parity"]["fixture"] is None and d["parity"]["sha256_matches_reference"] is None and "parity_failed" not in d

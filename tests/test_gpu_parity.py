@@ -122,6 +122,35 @@ def test_row_subsets_and_local_rows(dev):
     ctx.close()
 
 
+def test_kernel_timeline_sums_the_launches_of_a_loop(dev):
+    """gkmhip_kernel_timeline (what bench.py's kernel_ms comes from): while on, every launch keeps its own pair of HIP
+    events, so a loop enqueued without host waits can be read afterwards -- launches counted, the sum close to launches x
+    one launch; off again, the most recent launch's time is what gkmhip_last_kernel_ms returns, as before."""
+    import torch
+    seqs = helpers.synth_codes(300, 300, 300)
+    n = len(seqs)
+    ctx = dev.GramContext(4, 11, 7, 3)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.set_sequences(seqs, stream)
+    G = torch.zeros((n, n), dtype=torch.float64, device="cuda")
+    rows = np.arange(n)
+    ctx.gram_rows(rows, G.data_ptr(), n, None, 0, False, stream)
+    torch.cuda.synchronize()
+    one = ctx.last_kernel_ms()
+    assert one > 0
+    ctx.kernel_timeline(True)
+    for _ in range(5):
+        ctx.gram_rows(rows, G.data_ptr(), n, None, 0, False, stream)
+    total, launches = ctx.kernel_timeline_ms()
+    assert launches == 5 and 0.5 * 5 * one < total < 2.0 * 5 * one
+    ctx.kernel_timeline(False)
+    assert ctx.kernel_timeline_ms() == (0.0, 0)
+    ctx.gram_rows(rows, G.data_ptr(), n, None, 0, False, stream)
+    torch.cuda.synchronize()
+    assert 0.5 * one < ctx.last_kernel_ms() < 2.0 * one
+    ctx.close()
+
+
 def test_profile_symmetry_property(dev):
     """Size-independent property: P_m(a,j) computed with a as the row equals P_m(j,a) with j as
     the row.  Checked by reversing the sequence order."""
