@@ -302,6 +302,36 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
         ctx->minlen = std::min(ctx->minlen, (int)len);
     }
     ctx->n = n;
+    /* What share of the l-mer pairs of THESE sequences lies within d mismatches?  `auto` chooses between the bit-sliced and
+     * the general kernel by that share (gkm_gram.hip auto_takes_bitslice); the iid formula is exact for random ACGT and
+     * too low for repeat-rich or low-complexity input, so 8 192 l-mer pairs are sampled here on the host -- random
+     * sequence pairs, random positions, either strand of the second one, a fixed generator: ~0.2 ms, and the choice of
+     * kernel never changes a result. */
+    {
+        uint64_t st = 0x9E3779B97F4A7C15ull ^ (uint64_t)n;
+        auto next = [&]() { /* splitmix64 */
+            uint64_t z = (st += 0x9E3779B97F4A7C15ull);
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+            z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+            return z ^ (z >> 31);
+        };
+        const int samples = 8192;
+        int within = 0;
+        for (int t = 0; t < samples; t++) {
+            const int a = (int)(next() % (uint64_t)n), b = (int)(next() % (uint64_t)n);
+            const int la = ctx->h_len[(size_t)a], lb = ctx->h_len[(size_t)b];
+            const int p = (int)(next() % (uint64_t)(la - L + 1)), q = (int)(next() % (uint64_t)(lb - L + 1));
+            const bool rc = (next() & 1u) != 0;
+            const uint8_t *sa = codes + offsets[a] + p, *sb = codes + offsets[b];
+            int mm = 0;
+            for (int i = 0; i < L && mm <= ctx->d; i++) {
+                const uint8_t cb = rc ? (uint8_t)(3 - sb[lb - 1 - (q + i)]) : sb[q + i]; /* reverse complement: libgkm.c:877-888 */
+                mm += sa[i] != cb;
+            }
+            within += mm <= ctx->d;
+        }
+        ctx->sampled_hit_share = (double)within / samples;
+    }
     if (weighted && (wdist_len <= (ctx->maxlen - L + 1) / 2 || wdist_len > WD_LDS))
         return set_err_msg("distance weight table must cover 0..max(n)/2 and hold at most 1024 entries", 3);
     const size_t total = (size_t)offsets[n];

@@ -199,12 +199,21 @@ static double iid_hit_share(int L, int d)
 #ifndef GKM_BITSLICE_MAX_HIT_SHARE
 #define GKM_BITSLICE_MAX_HIT_SHARE 0.075
 #endif
-static bool auto_takes_bitslice(int L, int d) { return iid_hit_share(L, d) <= GKM_BITSLICE_MAX_HIT_SHARE; }
+/* The share `auto` goes by: the iid one, or what set_sequences sampled on the uploaded sequences when that is HIGHER by more
+ * than three standard deviations of its sampling noise (8 192 pairs: 0.28 % at the threshold) -- repeats and
+ * low-complexity input push real data above the iid rate, never far below it. */
+static double decisive_hit_share(const gkmhip_ctx *ctx)
+{
+    const double iid = iid_hit_share(ctx->L, ctx->d);
+    const double noise = 3.0 * sqrt(iid * (1.0 - iid) / 8192.0);
+    return ctx->sampled_hit_share > iid + noise ? ctx->sampled_hit_share : iid;
+}
+static bool auto_takes_bitslice(const gkmhip_ctx *ctx) { return decisive_hit_share(ctx) <= GKM_BITSLICE_MAX_HIT_SHARE; }
 
 bool bitslice_serves(const gkmhip_ctx *ctx)
 {
     if (ctx->kernel_pref == GKMHIP_KERNEL_DIRECT || !gkm_pick_bitslice(2, ctx->L, ctx->d)) return false;
-    return ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE || auto_takes_bitslice(ctx->L, ctx->d);
+    return ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE || auto_takes_bitslice(ctx);
 }
 
 
@@ -525,8 +534,9 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
     ctx->ev_valid = true;
     ctx->last_comparisons = comparisons;
     if (getenv("GKM_TRACE")) /* which kernel served this launch, and the rule's input: a regression on data far from iid shows here */
-        fprintf(stderr, "gkmhip: %d rows -> %s (preference %d; iid hit share of (L=%d, d=%d) %.4f, bit-sliced up to %.3f)\n", nrows,
-                ctx->last_kernel, ctx->kernel_pref, L, d, iid_hit_share(L, d), (double)GKM_BITSLICE_MAX_HIT_SHARE);
+        fprintf(stderr, "gkmhip: %d rows -> %s (preference %d; hit share of (L=%d, d=%d): iid %.4f, sampled on these sequences %.4f; "
+                        "bit-sliced up to %.3f)\n", nrows, ctx->last_kernel, ctx->kernel_pref, L, d, iid_hit_share(L, d),
+                ctx->sampled_hit_share, (double)GKM_BITSLICE_MAX_HIT_SHARE);
     return 0;
 }
 

@@ -330,6 +330,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
                 else ia = __usad(c0b, i0 | 2048u, v_rowbase); /* (offset in a VGPR: |q - centre| + offset would name two SGPRs) */
                 if (POSTAB) ib = (q ^ s_wsign) + s_wbase;
                 else ib = __usad(q + s_wbase, ccen, v_rowbase);
+                /* (Round 5 also read the weight bytes in PAIRS -- this window's and its neighbour's, for the second hit of the
+                 * visit below, as one 16-bit LDS read each: two LDS operations fewer per trip -- and lost 58 % on gkmQC's
+                 * shape (563 against 357 ms, profiles/r5_kernel_ab_hit_path.txt): half of those reads sit at odd addresses,
+                 * and whatever the hardware does with a misaligned ds_read_u16, it is no single LDS operation.  Not
+                 * pursued with an aligned layout: two bytes per position would cost the LDS allocation granule.) */
                 wa = wdb[ia];
                 wb = wdb[ib];
                 /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
@@ -447,7 +452,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             {
                 /* is the same bit of the record's NEXT word set (the record still sits in the list where it was read)?
                  * Not for the group's last word (sel = 4: what follows is the origin word). */
-                const uint32_t nxt = *(const uint32_t *)(at + ((sel + 1u) << 9));
+                /* (PARTIAL: the lanes past the last record hold no hit word, `first` is all ones: keep their read inside the list) */
+                const uint32_t nxt = *(const uint32_t *)(at + (((PARTIAL ? sel & 3u : sel) + 1u) << 9));
                 static_assert(BS_CAP * 4 == 512, "word g of a record is g * 512 bytes on");
                 cont = ((nxt >> bit) & 1u) & ~(first >> 7);
             }

@@ -133,6 +133,7 @@ struct gkmhip_ctx {
     size_t tl_used = 0;
     bool tl_on = false;
     hipEvent_t last_e0 = nullptr, last_e1 = nullptr;
+    double sampled_hit_share = -1.0; /* share of sampled l-mer pairs of THESE sequences within d mismatches (set_sequences) */
     double last_comparisons = 0;
     const char *last_kernel = "none";
 };

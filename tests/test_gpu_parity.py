@@ -347,6 +347,21 @@ def test_auto_takes_the_faster_kernel(dev):
             assert other["kernel"] != auto["kernel"]
             assert (auto["P"].cpu().numpy()[il] == other["P"].cpu().numpy()[il]).all()
             assert (auto["K"].cpu().numpy() == other["K"].cpu().numpy()).all()
+    # ... and by what the uploaded sequences themselves say (round 5: 8 192 sampled l-mer pairs at upload) where that is
+    # far above the iid rate: low-complexity input -- poly-A with a few substitutions -- has nearly every window pair
+    # within d = 3 of 11, which would put every lane of every trip to work: the general kernel, same numbers
+    low = []
+    for n in rng.integers(100, 320, 60):
+        x = np.zeros(int(n), dtype=np.uint8)
+        at = rng.integers(0, int(n), 4)
+        x[at] = rng.integers(0, 4, 4)
+        low.append(x)
+    il2 = np.tril_indices(len(low))
+    auto = dev.gram_matrix(low, 4, 11, 7, 3, want_profiles=True)
+    forced = dev.gram_matrix(low, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    assert auto["kernel"] == "k_gram_direct" and "bitslice" in forced["kernel"]
+    assert (auto["P"].cpu().numpy()[il2] == forced["P"].cpu().numpy()[il2]).all()
+    assert (auto["K"].cpu().numpy() == forced["K"].cpu().numpy()).all()
 
 
 def test_general_kernel_with_several_columns_per_workgroup(dev):
