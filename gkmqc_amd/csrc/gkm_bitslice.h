@@ -456,6 +456,18 @@ GKM_HD uint32_t pk_word(const uint8_t *codes, int len, int strand, int x)
     }
     return v;
 }
+/* the same with the strand continued cyclically behind its end (base i = base i mod len) */
+GKM_HD uint32_t pk_word_cyclic(const uint8_t *codes, int len, int strand, int x)
+{
+    uint32_t v = 0u;
+    int i = (x * 16) % len;
+    for (int k = 0; k < 16; k++) {
+        const uint32_t c = strand ? (3u - codes[len - 1 - i]) : codes[i];
+        v |= c << (2 * k);
+        if (++i == len) i = 0;
+    }
+    return v;
+}
 GKM_HD uint32_t pk_window(uint32_t lo, uint32_t hi, int pos)
 {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -232,23 +232,38 @@ __global__ void k_pack_strands(const uint8_t *__restrict__ codes, const int64_t 
     const int e = blockIdx.x, s = e >> 1, strand = e & 1;
     const uint8_t *seq = codes + off[s];
     const int T = (int)(off[s + 1] - off[s]);
+    /* CYCLIC (round 5): base i of the image is base i mod T of the strand, as in the bit planes of the counting loop, so
+     * that a 16-base window read near the strand's end holds the l-mers the counting loop compared there (the
+     * same-length variant's trips evaluate five consecutive windows from one such read) */
     for (int x = threadIdx.x; x < pkw; x += blockDim.x)
-        colpk[((size_t)s * pkw + x) * 2 + strand] = gkmbs::pk_word(seq, T, strand, x);
+        colpk[((size_t)s * pkw + x) * 2 + strand] = gkmbs::pk_word_cyclic(seq, T, strand, x);
 }
 
-/* one workgroup per sequence: its positional weights as the hit path's column side wants them in LDS -- byte L - 1 + p =
- * wt[p] = wd[|n/2 - p|] for the l-mers p < n (libgkm.c:912-925), zero bytes before (L - 1 of them) and behind (to the end of
- * the ptw words): a window that wraps around the end of the strand reads a zero (k_gram_bitslice POSTAB) */
+/* one workgroup per sequence: its positional weights as the hit path wants them in LDS (layout: gkm_gram_bitslice.h
+ * POSTAB_PAD): byte PAD + L - 1 + p = wt[p] = wd[|n/2 - p|] for the l-mers p < n (libgkm.c:912-925), L - 1 zero bytes either
+ * side -- a window that runs over the end of the strand reads a zero --, and outside those the weights of the windows past
+ * the end (l-mer j again: wt[j] behind, wt[n-1-j] in front for the reverse strand), zeros to the end of the ptw words */
 __global__ void k_build_postab(const int64_t *__restrict__ off, int L, const uint8_t *__restrict__ wd, int ptw,
                                uint32_t *__restrict__ postab)
 {
     const int s = blockIdx.x;
-    const int n = (int)(off[s + 1] - off[s]) - L + 1;
+    const int T = (int)(off[s + 1] - off[s]);
+    const int n = T - L + 1, PAD = (int)POSTAB_PAD;
+    auto wt = [&](int p) -> uint32_t {
+        if (p < 0 || p >= n) return 0u;
+        const int dd = n / 2 - p;
+        return wd[dd < 0 ? -dd : dd];
+    };
     for (int x = threadIdx.x; x < ptw; x += blockDim.x) {
         uint32_t v = 0u;
         for (int b = 0; b < 4; b++) {
-            const int p = x * 4 + b - (L - 1), dd = n / 2 - p;
-            if (p >= 0 && p < n) v |= (uint32_t)wd[dd < 0 ? -dd : dd] << (8 * b);
+            const int i = x * 4 + b;          /* byte index */
+            const int p = i - PAD - (L - 1);  /* l-mer position the byte stands for */
+            uint32_t w = 0u;
+            if (i < PAD) w = wt(n - 1 - (PAD - 1 - i));          /* in front: index PAD-1-j is l-mer n-1-j */
+            else if (p >= 0 && p < n) w = wt(p);
+            else if (p >= T && p < T + PAD) w = wt(p - T);       /* behind the zeros: position T + j is l-mer j */
+            v |= w << (8 * b);
         }
         postab[(size_t)s * ptw + x] = v;
     }
@@ -395,7 +410,8 @@ int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
 int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream)
 {
     if (ctx->have_postab) return 0;
-    const int ptw = (ctx->maxlen + ctx->L - 1 + 3) / 4;
+    /* (+ 8: the same-length variant reads the bytes as aligned pairs of words around index .. index + 4) */
+    const int ptw = ((int)POSTAB_PAD + ctx->L - 1 + ctx->maxlen + (int)POSTAB_PAD + 8 + 3) / 4;
     if (ctx->postab.ensure((size_t)ctx->n * (size_t)ptw)) return 4;
     hipLaunchKernelGGL(k_build_postab, dim3((unsigned)ctx->n), dim3(64), 0, stream, ctx->off.p, ctx->L, ctx->wd.p, ptw,
                        ctx->postab.p);

@@ -252,10 +252,16 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
          * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
         /* (a jump in the row list -- a multi-GPU rank's two folded row blocks -- closes the tile where that means fewer
          * work items: gkm_pack.h) */
+        /* same-length problems (the same-length kernel variant, PK = 4, evaluates groups of five lane positions at once:
+         * full lanes own a multiple of five windows; L >= 5: the zero bytes behind its weight table must cover a group) */
+        const bool same_length = ctx->minlen == ctx->maxlen;
+        const bool want_unif = same_length && L >= 5 && getenv("GKM_NO_UNIF") == nullptr && getenv("GKM_FORCE_PACKED") == nullptr &&
+                               gkm_pick_bitslice(4, L, d) != nullptr;
+        const int own_mult = want_unif ? 5 : 1;
         auto pack = [&](int max_rows) {
-            gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows);
+            gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, 0, own_mult);
             if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
-            gkmpack::Packing b = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, gkmpack::LANES);
+            gkmpack::Packing b = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, gkmpack::LANES, own_mult);
             return gkmpack::triangle_items(b) < gkmpack::triangle_items(a) ? b : a;
         };
         gkmpack::Packing pk = pack(64);
@@ -285,9 +291,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
          * column's table by position); several-pieces variants: the distance table alone. */
         const size_t wd_bytes = (size_t)((ctx->wd_len + 3) / 4) * 4;
         const size_t postab_bytes = (size_t)ctx->ptw * 4;
-        const bool same_length = ctx->minlen == ctx->maxlen;
         /* same-length problems, one piece per lane: the variant that needs neither piece table nor permute (PK = 4) */
-        const bool unif = !packed && same_length && getenv("GKM_NO_UNIF") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
+        const bool unif = !packed && want_unif;
         const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
                                (packed ? wd_bytes : postab_bytes + (unif ? 0 : wd_bytes));
         static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
@@ -305,6 +310,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                 bperm = true;
             if (bperm) bs = bsp;
         }
+        auto nwin_of = [&](int row) { return ctx->h_len[(size_t)row] - L + 1; };
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
         std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)LPW, 0u);
@@ -327,8 +333,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             } else if (unif) {
                 /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index
                  * is the piece's first position over the lane capacity: pieces of a same-length problem fill whole lanes */
-                const int cap = gkmbs::segment_capacity(W, L);
-                if (pc.b0 != 0 || pc.p0 % cap != 0 || pc.p0 / cap > 7 || slot4 / 4 > 63)
+                const int cap = gkmbs::segment_capacity(W, L) / 5 * 5; /* (own_mult = 5) */
+                if (pc.b0 != 0 || pc.p0 % cap != 0 || pc.p0 / cap > 7 || slot4 / 4 > 63 || (pc.cnt % 5 != 0 && pc.p0 + pc.cnt != nwin_of(pc.row)))
                     return set_err_msg("gram: same-length packing broke its own rule", 2);
                 lane_piece[(size_t)pc.lane * 2] = ((slot4 / 4u) << gkmbs::META_SLOT_SHIFT) |
                                                   ((uint32_t)(pc.p0 / cap) << gkmbs::META_PIECE_SHIFT);
@@ -450,6 +456,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
         A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
         A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
+        A.cap = gkmbs::segment_capacity(W, L) / 5 * 5;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];

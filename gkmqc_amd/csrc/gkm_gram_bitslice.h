@@ -18,6 +18,7 @@ struct BsArgs {
     int rpw, pkw, wd_words;     /* wd_words: dwords of wd8 that hold weights (the kernels copy that many to LDS) */
     const uint32_t *postab;     /* [seq][ptw] every sequence's weights BY POSITION, L - 1 zero bytes either side (k_build_postab):
                                  * what the one-piece variants keep in LDS for the column (k_gram_bitslice POSTAB) */
+    int cap;                    /* same-length variant: l-mer windows a full lane owns (a multiple of 5: gkm_pack.h own_mult) */
     int ptw, ptw_stride;        /* ptw_stride = ptw, or 0 when every sequence has the same length: one table, which then stays
                                  * in the CUs' L1 instead of 0.3-0.6 KB per column coming from L2 (config 2: 1 % of the kernel) */
     const uint32_t *sb;
@@ -59,6 +60,13 @@ typedef const uint32_t __attribute__((address_space(4))) * sgpr_words;
                        176.2, 4 -> 76.4-76.8 / 436.7-438.6 / 175.6-175.8, 5, 6, 8 -> 79.1-79.4 / 452-454 / 176.5 */
 #endif
 constexpr int BS_DU = GKM_BS_DU; /* shifts per SB register refill (the SB tables are padded by it: ensure_sb) */
+
+/* The positional weight table of a sequence with n l-mers (k_build_postab), bytes:
+ *   [POSTAB_PAD: wt[n-5 .. n-1]] [L - 1 zeros] [wt[0 .. n-1]] [L - 1 zeros] [POSTAB_PAD: wt[0 .. 4]] [zeros to the end]
+ * byte POSTAB_PAD + L - 1 + p = wt[p].  The zeros serve the windows that run over the strand's end (no l-mers); the five
+ * bytes behind them the windows PAST the end -- position T + j is l-mer j again -- and the five bytes in front the same on
+ * the reverse strand, whose weights are read downwards (wt_rc[q] = wt[n-1-q], libgkm.c:924). */
+constexpr uint32_t POSTAB_PAD = 5;
 
 typedef void (*bs_kernel_t)(const BsArgs);
 /* the instantiation for W = 10 words per lane and packing variant pk (k_gram_bitslice's PK), or nullptr */

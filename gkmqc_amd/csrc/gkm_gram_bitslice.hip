@@ -132,7 +132,12 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
      * that would leave lanes empty (many rows shorter than half a lane). */
     constexpr int NP = PACKED ? gkmpack::MAX_PIECES : 1;   /* pieces per lane */
     constexpr int NSLOT = PK == 2 ? gkmpack::MAX_ROWS : 64; /* row slots per tile */
-    constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = (BS_GRP + 1) * BS_CAP, LMASK_WORDS = PACKED ? 64 : 0;
+    /* GROUP (the same-length variant): a record of the hit list is TWO words -- the OR of the group's five hit words
+     * (which bit rows of the lane hold a hit somewhere in the group) and the origin -- and a trip finds the hits among the
+     * five windows of (bit row, group) itself, from the packed strands it reads anyway (see trip_group). */
+    constexpr bool GROUP = UNIF;
+    constexpr int LIST_ARRAYS = GROUP ? 2 : BS_GRP + 1;
+    constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = LIST_ARRAYS * BS_CAP, LMASK_WORDS = PACKED ? 64 : 0;
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
     constexpr int LPIECE_WORDS = PACKED ? 64 * NP : (BPERM || UNIF) ? 0 : 128;
@@ -256,7 +261,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             for (int x = lane; x < A.ptw; x += 64) ((uint32_t *)s_wtab)[x] = A.postab[(size_t)j * A.ptw_stride + x];
             if (!UNIF)
                 for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = ((const uint32_t *)A.wd8)[x];
-            s_rowbase = (uint32_t)pkw * 8u + (UNIF ? (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u);
+            s_rowbase = (uint32_t)pkw * 8u + (UNIF ? POSTAB_PAD + (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u) +
+                        (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u); /* (GROUP: an LDS address, not an offset into s_dyn) */
         } else {
             for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)s_wtab)[x] = ((const uint32_t *)A.wd8)[x];
             s_rowbase = (uint32_t)pkw * 8u;
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
          *   POSTAB:  s_wsign 0 / ~0, s_wbase: the column weight's LDS byte is (q ^ s_wsign) + s_wbase = L-1 + q or
          *            L-1 + nB-1 - q behind the table's start
          *   !POSTAB: s_wbase = [reverse strand and nB even]: wt_rc[q] = wt[nB-1-q] = wd[|q + [nB even] - nB/2|] */
-        uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u, s_wstep = 1u;
+        uint32_t s_strand4 = 0u, s_wsign = 0u, s_wbase = 0u, s_wstep = 1u, s_wback = 0u, s_perm4 = 0x03020100u, s_perm1 = 0x0c0c0c04u;
         uint32_t v_rowbase = 0u;
         if (!POSTAB) asm volatile("v_mov_b32 %0, %1" : "=v"(v_rowbase) : "s"(s_rowbase));
 #pragma unroll
@@ -477,6 +483,96 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             }
             __builtin_amdgcn_s_setprio(0);
         };
+        /* GROUP: one trip over the `c` two-word records on top of the list.  A record says: some of the five windows
+         * (bit row b, words w0 .. w0+4) of source lane r are hits.  Lane positions i0 .. i0+4 (i0 = 10 b + w0) are five
+         * CONSECUTIVE l-mers of the row against five consecutive l-mers q .. q+4 of the column strand, and the two 16-base
+         * windows that the hit path fetches anyway -- one v_alignbit_b32 per side -- hold all of them (5 + L - 1 <= 16
+         * bases): the mismatch count of window k is the popcount of a bit field of ONE folded XOR word.  So the visit
+         * resolves every hit of the (bit row, group) at once: no search through five hit words, no copy of the record
+         * back with one bit cleared per hit, and the counting loop pushes 8 bytes per record instead of 24 (round 5: the
+         * pushes, two per shift whatever the hits, cost 14 % of config 2's kernel and 23 % of gkmQC's shape when doubled
+         * -- profiles/r5_trip_sensitivity.txt).
+         * What makes every window of a pushed group safe to evaluate without its hit bit:
+         *   row side     the lanes of a same-length problem own window counts that are multiples of 5 (gkm_pack.h
+         *                own_mult), so a group is owned whole or not at all; windows past the row's last l-mer (the
+         *                row's last lane) read the zero bytes behind the positional weight table;
+         *   column side  the packed strands are CYCLIC (k_pack_strands), so a window that runs over the strand's end is
+         *                the very l-mer the cyclic bit planes of the counting loop compared; it is not an l-mer of the
+         *                sequence and reads a zero weight (the L - 1 zero bytes); a window PAST the end (q + k >= T) is
+         *                the strand's k-th l-mer again and reads its weight from the five bytes behind / before the
+         *                zeros (k_build_postab);
+         *   m <= d       is tested per window (EXEC-masked ds_add): unlike the single-hit path this one looks at
+         *                windows the counting loop did not flag. */
+        auto trip_group = [&](auto partial_tag, int c) {
+            constexpr bool PARTIAL = decltype(partial_tag)::value;
+            __builtin_amdgcn_s_setprio(GKM_TRIP_PRIO);
+            const uint32_t top4 = (uint32_t)__builtin_amdgcn_readfirstlane((s_n - c) << 2);
+            uint32_t at_off;
+            asm("v_add_u32 %0, %1, %2" : "=v"(at_off) : "s"(top4), "v"(lane4));
+            const char *const at = (const char *)s_list + at_off;
+            uint32_t any = *(const uint32_t *)at;
+            const uint32_t ms = *(const uint32_t *)(at + BS_CAP * 4);
+            if (PARTIAL) any = (lane < c) ? any : 0u;
+            const uint32_t bit = ffbl_or_ones(any);
+            const uint32_t rest = any & (any - 1u); /* the other bit rows of the group with a hit: back to the list */
+            if (!PARTIAL || any) {
+                const uint32_t lane128 = ms & (63u << META_LANE_SHIFT);
+                const uint32_t slot4 = (ms >> (META_SLOT_SHIFT - 2)) & 0xFCu;
+                const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 15u);
+                const uint32_t x = i0 + (ms >> 21);
+                uint32_t q;
+                if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
+                else q = mod_small(x, (uint32_t)T, rcpT);
+                const uint32_t *rw = (const uint32_t *)(rowpk_tile + lop3<0xEA>(i0 >> 2, ~3u, lane128));
+                typedef const uint32_t __attribute__((address_space(3))) *lds_words;
+                const uint32_t cwo = lop3<0xEA>(q >> 1, ~7u, s_strand4);
+                const lds_words cw = COL_BASE_FOLDS ? (lds_words)(uintptr_t)cwo : (lds_words)(uintptr_t)((uint32_t)(STATIC_WORDS * 4) + cwo);
+                /* the five weight bytes of either side as (four bytes, one byte): an aligned pair of LDS words around the
+                 * first byte, funnel-shifted to it.  Row: bytes ia .. ia+4 of the positional table (l-mers p .. p+4).
+                 * Column: ib .. ib+4 on the forward strand; the reverse strand's weights are the forward ones mirrored
+                 * (libgkm.c:924), bytes ib, ib-1, .., ib-4: fetched from ib-4 up and turned round by v_perm_b32 with
+                 * strand-uniform selectors. */
+                const uint32_t ia = __umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)A.cap) + i0 + s_rowbase;
+                const uint32_t ib = (q ^ s_wsign) + s_wbase;      /* this window's byte */
+                const uint32_t il = ib - s_wback;                 /* the lowest of the five addresses (s_wback = 4 on the reverse strand) */
+                /* (ia, ib are LDS ADDRESSES here: s_rowbase and s_wbase include the dynamic LDS's start, below) */
+                const lds_words pa = (lds_words)(uintptr_t)(ia & ~3u);
+                const lds_words pb = (lds_words)(uintptr_t)(il & ~3u);
+                const uint32_t a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
+                const uint32_t sha = (ia & 3u) << 3, shb = (il & 3u) << 3;
+                const uint32_t wa4 = __builtin_amdgcn_alignbit(a1, a0, sha), wa1 = a1 >> sha;
+                const uint32_t lo = __builtin_amdgcn_alignbit(b1, b0, shb), hi = b1 >> shb;
+                const uint32_t wb4 = __builtin_amdgcn_perm(hi, lo, s_perm4), wb1 = __builtin_amdgcn_perm(hi, lo, s_perm1);
+                /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
+                const uint32_t ea = __builtin_amdgcn_alignbit(rw[1], rw[0], twice(i0));
+                const uint32_t eb = __builtin_amdgcn_alignbit(cw[2], cw[0], twice(q));
+                uint32_t t = ea ^ eb;
+                t = (t | (t >> 1)) & 0x55555555u; /* one bit per mismatching base of the 16 */
+                static_assert(5 + L - 1 <= 16, "the five windows of a group lie inside one 16-base window");
+#pragma unroll
+                for (int k = 0; k < 5; k++) {
+                    const uint32_t m = (uint32_t)__builtin_popcount(__builtin_amdgcn_ubfe(t, 2u * k, 2u * L));
+                    const uint32_t wa = k < 4 ? ((wa4 >> (8 * k)) & 0xFFu) : (wa1 & 0xFFu);
+                    const uint32_t wb = k < 4 ? ((wb4 >> (8 * k)) & 0xFFu) : (wb1 & 0xFFu);
+                    if (m <= (uint32_t)D) /* LDS atomic: ds_add_u32 (a window that is no l-mer adds 0) */
+                        atomicAdd((uint32_t *)((char *)accl + (m * (uint32_t)(NSLOT * 4) + slot4)), wa * wb);
+                }
+            }
+            s_n -= c;
+            const unsigned long long more = __ballot(rest != 0u);
+            if (more) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(more >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)more, 0u));
+                if (rest != 0u) {
+                    char *const to = (char *)s_list + ((rank + (uint32_t)s_n) << 2);
+                    *(uint32_t *)to = rest;
+                    *(uint32_t *)(to + BS_CAP * 4) = ms;
+                }
+                s_n += (int)__popcll(more);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        };
+
         /* Resolve the hit list in FULL trips of 64 records with every lane busy: each record gives up
          * its first hit (lowest bit of its first non-empty word), a record with more hits is appended
          * again.  Fewer than one trip's worth of records waits in the list; the last call of a column
@@ -485,12 +581,16 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
          * (v_ffbl_b32 gives all ones for an empty word, so empty words lose the min), the number of
          * hits left is a popcount sum, and a record that goes back to the list is copied unchanged and
          * then loses that hit by ONE LDS xor on the copy (the LDS operations of a wave execute in order). */
+        auto one_trip = [&](auto partial_tag, int c) {
+            if constexpr (GROUP) trip_group(partial_tag, c);
+            else trip(partial_tag, c);
+        };
         auto trips = [&](bool final) {
-            while (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
+            while (s_n >= BS_TRIP) one_trip(std::false_type(), BS_TRIP);
             if (final)
                 while (s_n > 0) {
-                    if (s_n >= BS_TRIP) trip(std::false_type(), BS_TRIP);
-                    else trip(std::true_type(), s_n);
+                    if (s_n >= BS_TRIP) one_trip(std::false_type(), BS_TRIP);
+                    else one_trip(std::true_type(), s_n);
                 }
         };
 
@@ -498,7 +598,13 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             s_strand4 = (uint32_t)strand * 4u + (COL_BASE_FOLDS ? (uint32_t)(STATIC_WORDS * 4) : 0u);
             s_wsign = strand ? ~0u : 0u;
             s_wstep = strand ? ~0u : 1u; /* POSTAB: the next window's weight byte is the next / the previous one */
-            if (POSTAB) s_wbase = (uint32_t)pkw * 8u + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u); /* ~q = -q - 1 */
+            /* GROUP: the five column weights start 4 bytes lower on the reverse strand and are turned round; selectors of
+             * v_perm_b32(hi, lo): byte k of the result is byte sel_k of (hi:lo) */
+            s_wback = strand ? 4u : 0u;
+            s_perm4 = strand ? 0x01020304u : 0x03020100u;
+            s_perm1 = strand ? 0x0c0c0c00u : 0x0c0c0c04u;
+            if (POSTAB) s_wbase = (uint32_t)pkw * 8u + POSTAB_PAD + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u) + /* ~q = -q - 1 */
+                                  (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u);
             else s_wbase = (strand && !(nB & 1)) ? 1u : 0u;
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */
@@ -539,9 +645,13 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
                                                                             __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
                             if (any != 0u) {
                                 char *const at = (char *)s_list + (((uint32_t)rank + (uint32_t)s_n) << 2);
+                                if (GROUP) { /* 8 bytes per record instead of 24: one ds_write2st64_b32 */
+                                    *(uint32_t *)at = any;
+                                } else {
 #pragma unroll
-                                for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
-                                *(uint32_t *)(at + BS_GRP * BS_CAP * 4) = vbase | (uint32_t)w0;
+                                    for (int g = 0; g < BS_GRP; g++) *(uint32_t *)(at + g * BS_CAP * 4) = hit[w0 + g];
+                                }
+                                *(uint32_t *)(at + (LIST_ARRAYS - 1) * BS_CAP * 4) = vbase | (uint32_t)w0;
                             }
                             s_n += (int)__popcll(mask);
                             if (s_n >= BS_TRIP) trips(false);

@@ -54,8 +54,11 @@ struct Packing {
  * tile's largest row, so low rows that share a tile with high ones ride along through thousands of columns they do not
  * need: rank 0 of an 8-way split of config 2 ran 109 660 work items instead of 100 760 (round 5,
  * profiles/r5_small_launch_blocks.txt).  Whether splitting pays depends on the list (it can also cost a tile); the caller
- * packs both ways and keeps the one with fewer work items (triangle_items). */
-inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows = MAX_ROWS, int split_jump = 0)
+ * packs both ways and keeps the one with fewer work items (triangle_items).
+ * own_mult: a piece that does not finish its row owns a multiple of that many windows (the same-length kernel variant
+ * evaluates GROUPS of five consecutive lane positions at once and needs every group owned whole or not at all). */
+inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int L, int max_rows = MAX_ROWS, int split_jump = 0,
+                         int own_mult = 1)
 {
     Packing P;
     P.W = W;
@@ -92,7 +95,8 @@ inline Packing pack_rows(const int *rows, const int *nwin, int nrows, int W, int
                  * tile take the several-pieces-per-lane path; a partial piece must hold >= 3W windows
                  * (config 2 with 10-window slivers in the 2 spare bit rows: 119 ms instead of 113) */
                 const int want = need < freeb ? need : freeb;
-                const int cnt_here = want * W - (L - 1) < remaining ? want * W - (L - 1) : remaining;
+                const int room = want * W - (L - 1); /* windows a piece of `want` bit rows can own */
+                const int cnt_here = room >= remaining ? remaining : room / own_mult * own_mult;
                 if (freeb < min_bits || npl >= MAX_PIECES || (want < need && cnt_here < 3 * W)) {
                     new_lane();
                     if (lane >= LANES) { fits = false; break; }

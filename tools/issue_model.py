@@ -7,7 +7,7 @@ v_lshrrev / v_ashrrev / v_bitop3 on VGPRs, literals and inline constants) about 
 v_cndmask, SDWA / DPP forms, packed 16-bit operations, and any instruction with an SGPR source -- about every 4.2
 (tools/valu_ops.hip, profiles/r3_valu_ops.txt).  This script disassembles one k_gram_bitslice instantiation, prices every
 VALU instruction with those two rates, and splits the kernel into the counting loop (everything outside the trips,
-per shift) and one trip (between the ring read that precedes the first v_ffbl_b32 and the ds_xor_b32 that ends it).
+per shift) and one trip (between the s_setprio that raises the wave's priority and the s_setprio 0 that ends it).
 
     python3 tools/issue_model.py [--object gkmqc_amd/csrc/build/gkm_gram_bitslice.o] [--kernel 10,11,3,4] [--shifts-per-block 4]
         [--waves N --T len --trips N --ms measured]
@@ -107,25 +107,17 @@ def cost(lines):
 
 def analyse(obj, kernel, du):
     sym, lines = disassemble(obj, kernel)
-    # trips: every copy runs from the ring read (3 x ds_read2st64_b32) before a v_ffbl_b32 to the ds_xor_b32 after it
-    ffbl = [i for i, x in enumerate(lines) if x.startswith("v_ffbl_b32")]
-    starts = []
-    for i in ffbl:
-        if starts and i - starts[-1][1] < 40:
-            starts[-1][1] = i
-            continue
-        j = i
-        while j > 0 and not lines[j].startswith("ds_read2st64_b32"):
-            j -= 1
-        while j > 0 and lines[j - 1].startswith(("ds_read2st64_b32", "v_and_b32", "v_add_lshl_u32", "v_add_u32")):
-            j -= 1
-        starts.append([j, i])
+    # trips: every copy runs from the s_setprio that raises the wave's priority to the s_setprio 0 that ends it (both trip
+    # kinds: the single-hit one with its 3 x ds_read2st64_b32 ... ds_xor_b32, the same-length variant's group trip)
     copies = []
-    for j, i in starts:
-        k = i
-        while k < len(lines) and not lines[k].startswith("ds_xor_b32"):
-            k += 1
-        copies.append((j, k))
+    start = None
+    for i, x in enumerate(lines):
+        if x.startswith("s_setprio"):
+            if not x.split()[1].startswith("0"):
+                start = i
+            elif start is not None:
+                copies.append((start, i))
+                start = None
     in_trip = set()
     for j, k in copies:
         in_trip.update(range(j, k + 1))
