@@ -170,7 +170,7 @@ extern "C" void gkmhip_destroy(gkmhip_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     /* (hipFree waits for the work that may still use the buffers; no separate device-wide wait) */
-    ctx->codes.release(); ctx->wd.release(); ctx->off.release(); ctx->lmoff.release();
+    ctx->codes.release(); ctx->wd.release(); ctx->wdc.release(); ctx->off.release(); ctx->lmoff.release();
     ctx->len.release(); ctx->lmf.release(); ctx->sb.release(); ctx->colpk.release(); ctx->postab.release();
     for (auto &scr : ctx->scratch) scr.release();
     ctx->sq.release();
@@ -363,6 +363,18 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
     if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
     ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
+    {
+        /* the centred copy: byte centre + s = wd[|s|] for |s| < wd_len, 0 outside; 4 bytes of slack below and 12 above
+         * (k_gram_bitslice reads five consecutive bytes as an aligned pair of words) */
+        const int B = ctx->wd_len - 1, centre = B + 4, bytes = ((centre + B + 1 + 12 + 3) / 4) * 4;
+        std::vector<uint8_t> wdc((size_t)bytes, 0);
+        for (int sd = -B; sd <= B; sd++) wdc[(size_t)(centre + sd)] = weighted ? wdist[sd < 0 ? -sd : sd] : (uint8_t)1;
+        if (ctx->wdc.ensure((size_t)bytes / 4)) return 4;
+        HIPCHK(hipMemcpyAsync(ctx->wdc.p, wdc.data(), (size_t)bytes, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream)); /* (the source is a local vector) */
+        ctx->wdc_words = bytes / 4;
+        ctx->wdc_centre = centre;
+    }
     /* The per-sequence device tables are built HERE, not at the first launch: callers alternate launches between
      * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
      * second launch on the other stream before it was complete (found when the host stopped waiting for its

@@ -257,7 +257,9 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         const bool same_length = ctx->minlen == ctx->maxlen;
         const bool want_unif = same_length && L >= 5 && getenv("GKM_NO_UNIF") == nullptr && getenv("GKM_FORCE_PACKED") == nullptr &&
                                gkm_pick_bitslice(4, L, d) != nullptr;
-        const int own_mult = want_unif ? 5 : 1;
+        /* every bit-sliced variant with L >= 5 resolves hits by GROUPS of five lane positions (k_gram_bitslice GROUP): a
+         * piece that does not finish its row owns a multiple of five windows */
+        const int own_mult = L >= 5 ? 5 : 1;
         auto pack = [&](int max_rows) {
             gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, 0, own_mult);
             if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
@@ -278,6 +280,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* no lane with a second piece -> the leaner kernel variant */
         bool packed = getenv("GKM_FORCE_PACKED") != nullptr || slots != 64;
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
+        /* one piece per lane but ragged lengths: the several-pieces variant serves them too, and with L >= 5 it resolves
+         * hits by groups, which the table / permute variants (PK = 0, 3) do not */
+        if (!packed && !want_unif && L >= 5 && getenv("GKM_NO_UNIF") == nullptr) packed = true;
+        const bool pgroup = packed && L >= 5;
         const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
         bs_kernel_t bs = !packed ? gkm_pick_bitslice(0, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
         /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
@@ -294,7 +300,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         /* same-length problems, one piece per lane: the variant that needs neither piece table nor permute (PK = 4) */
         const bool unif = !packed && want_unif;
         const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
-                               (packed ? wd_bytes : postab_bytes + (unif ? 0 : wd_bytes));
+                               (pgroup ? postab_bytes + (size_t)ctx->wdc_words * 4 : packed ? wd_bytes : postab_bytes + (unif ? 0 : wd_bytes));
         static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
         if (unif) bs = gkm_pick_bitslice(4, L, d);
         bool bperm = false;
@@ -328,7 +334,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             const bool second = 2 * pk.tile_nrows[(size_t)tile_of] <= slots && (pc.lane & 1);
             const uint32_t slot4 = ((uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u)) * 4u;
             const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
-            if (packed) {
+            if (pgroup) { /* slot | centre offset << 7 | owned windows << 20 (k_gram_bitslice PGROUP) */
+                if (slot4 / 4 > 127 || c0b > 0x1FFFu || pc.cnt > 511) return set_err_msg("gram: piece entry out of range", 2);
+                lane_piece[(size_t)pc.lane * NP + k] = (slot4 / 4u) | (c0b << 7) | ((uint32_t)pc.cnt << 20);
+            } else if (packed) {
                 lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
             } else if (unif) {
                 /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index
@@ -457,6 +466,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
         A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
         A.cap = gkmbs::segment_capacity(W, L) / 5 * 5;
+        A.wdc = ctx->wdc.p; A.wdc_words = ctx->wdc_words; A.wdc_centre = ctx->wdc_centre;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
         A.len = ctx->len.p;
         for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];

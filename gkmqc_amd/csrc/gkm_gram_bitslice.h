@@ -18,6 +18,8 @@ struct BsArgs {
     int rpw, pkw, wd_words;     /* wd_words: dwords of wd8 that hold weights (the kernels copy that many to LDS) */
     const uint32_t *postab;     /* [seq][ptw] every sequence's weights BY POSITION, L - 1 zero bytes either side (k_build_postab):
                                  * what the one-piece variants keep in LDS for the column (k_gram_bitslice POSTAB) */
+    const uint32_t *wdc;        /* several-pieces group variants: the distance weights CENTRED, byte wdc_centre + s = wd[|s|] */
+    int wdc_words, wdc_centre;
     int cap;                    /* same-length variant: l-mer windows a full lane owns (a multiple of 5: gkm_pack.h own_mult) */
     int ptw, ptw_stride;        /* ptw_stride = ptw, or 0 when every sequence has the same length: one table, which then stays
                                  * in the CUs' L1 instead of 0.3-0.6 KB per column coming from L2 (config 2: 1 % of the kernel) */

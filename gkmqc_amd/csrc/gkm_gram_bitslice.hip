@@ -135,9 +135,10 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
     /* GROUP (the same-length variant): a record of the hit list is TWO words -- the OR of the group's five hit words
      * (which bit rows of the lane hold a hit somewhere in the group) and the origin -- and a trip finds the hits among the
      * five windows of (bit row, group) itself, from the packed strands it reads anyway (see trip_group). */
-    constexpr bool GROUP = UNIF;
+    constexpr bool GROUP = UNIF || (PACKED && L >= 5); /* (L >= 5: the L - 1 zero bytes of a weight table cover a group) */
+    constexpr bool PGROUP = GROUP && PACKED;
     constexpr int LIST_ARRAYS = GROUP ? 2 : BS_GRP + 1;
-    constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = LIST_ARRAYS * BS_CAP, LMASK_WORDS = PACKED ? 64 : 0;
+    constexpr int ACC_WORDS = (D + 1) * NSLOT, LIST_WORDS = LIST_ARRAYS * BS_CAP, LMASK_WORDS = (PACKED && !PGROUP) ? 64 : 0;
     /* per piece: row slot * 4 and the biased centre offset c0 + 2048 -- two words in the one-piece variant
      * (one ds_read_b64), one word (slot * 4 | c0b << 16) in the several-pieces variants */
     constexpr int LPIECE_WORDS = PACKED ? 64 * NP : (BPERM || UNIF) ? 0 : 128;
@@ -209,7 +210,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
     }
 
     /* one wavefront per workgroup: the LDS traffic of a wave is ordered, no barriers needed */
-    if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
+    /* (PGROUP: the piece-start mask stays in a register of its lane and a trip fetches it by ds_bpermute_b32 -- the 256
+     * bytes keep the wave inside four LDS allocation granules at 600 bp) */
+    uint32_t my_lmask = 0u;
+    if (PGROUP) my_lmask = A.lane_mask[tile * 64 + lane];
+    else if (PACKED) lmask[lane] = A.lane_mask[tile * 64 + lane];
     constexpr int LPW = PACKED ? NP : 2; /* lpiece words per lane */
     if (!BPERM && !UNIF) {
 #pragma unroll
@@ -256,13 +261,22 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
          * !POSTAB: one distance-indexed table for both sides, as rounds 2-4 had it. */
         const uint32_t ccen = (uint32_t)(nB / 2);
         uint32_t s_rowbase; /* LDS byte offset (from s_dyn) of the row side's wd[0] */
-        if (POSTAB) {
+        if (POSTAB || PGROUP) {
             /* (built once per sequence by k_build_postab, gkm_context.hip: the wave copies dwords, as it copies the strands) */
             for (int x = lane; x < A.ptw; x += 64) ((uint32_t *)s_wtab)[x] = A.postab[(size_t)j * A.ptw_stride + x];
-            if (!UNIF)
-                for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = ((const uint32_t *)A.wd8)[x];
-            s_rowbase = (uint32_t)pkw * 8u + (UNIF ? POSTAB_PAD + (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u) +
-                        (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u); /* (GROUP: an LDS address, not an offset into s_dyn) */
+            if (PGROUP) {
+                /* the row side's weights CENTRED: byte A.wdc_centre + s = wd[|s|] for the signed distance s of an l-mer to
+                 * its sequence's centre l-mer, so that five consecutive l-mers read five consecutive bytes (the host builds
+                 * it: gkm_gram.hip; it serves every row length) */
+                for (int x = lane; x < A.wdc_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = A.wdc[x];
+                /* (the l-mer at lane position i0 has the signed distance i0 + 2048 - c0b: its byte is at i0 - c0b + this) */
+                s_rowbase = (uint32_t)(STATIC_WORDS * 4) + (uint32_t)pkw * 8u + (uint32_t)A.ptw * 4u + (uint32_t)A.wdc_centre + 2048u;
+            } else {
+                if (!UNIF)
+                    for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)(s_wtab + A.ptw * 4))[x] = ((const uint32_t *)A.wd8)[x];
+                s_rowbase = (uint32_t)pkw * 8u + (UNIF ? POSTAB_PAD + (uint32_t)(L - 1) /* by position */ : (uint32_t)A.ptw * 4u) +
+                            (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u); /* (GROUP: an LDS address, not an offset into s_dyn) */
+            }
         } else {
             for (int x = lane; x < A.wd_words; x += 64) ((uint32_t *)s_wtab)[x] = ((const uint32_t *)A.wd8)[x];
             s_rowbase = (uint32_t)pkw * 8u;
@@ -515,10 +529,32 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             if (PARTIAL) any = (lane < c) ? any : 0u;
             const uint32_t bit = ffbl_or_ones(any);
             const uint32_t rest = any & (any - 1u); /* the other bit rows of the group with a hit: back to the list */
+            const uint32_t lane128 = ms & (63u << META_LANE_SHIFT);
+            /* PGROUP: the source lane's mask of piece-start bit rows, from that lane's register.  EVERY lane takes part
+             * (ds_bpermute_b32 reads 0 from lanes that EXEC masks out, and in a partial trip the source lane of a live
+             * record may well be a lane without a record) */
+            uint32_t lm = 0u;
+            if (PGROUP) lm = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(lane128 >> 5), (int)my_lmask);
             if (!PARTIAL || any) {
-                const uint32_t lane128 = ms & (63u << META_LANE_SHIFT);
-                const uint32_t slot4 = (ms >> (META_SLOT_SHIFT - 2)) & 0xFCu;
                 const uint32_t i0 = __umul24(bit, (uint32_t)W) + (ms & 15u);
+                uint32_t slot4, ia, nv = 5u; /* row slot * 4; LDS address of the row l-mer's weight; owned windows from i0 on */
+                if (PGROUP) {
+                    /* the piece of the source lane that owns bit row `bit`; its entry = slot | centre offset << 7 | owned
+                     * windows << 20 */
+                    const uint32_t below = lm & (0xFFFFFFFFu >> (31u - bit)); /* piece starts at or below the bit row */
+                    const uint32_t k = (uint32_t)__builtin_popcount(below) - 1u;
+                    const uint32_t b0 = 31u - (uint32_t)__builtin_clz(below);
+                    const uint32_t lp = *(const uint32_t *)((const char *)lpiece + ((lane128 >> 3) + (k << 2)));
+                    slot4 = (lp << 2) & 0x1FCu;
+                    const uint32_t c0b = (lp >> 7) & 0x1FFFu;
+                    /* a group is owned whole or not at all (piece counts are multiples of five) EXCEPT in a row's last
+                     * piece, whose windows end where the row does: the bytes of the windows behind are masked below */
+                    nv = (lp >> 20) - (i0 - __umul24(b0, (uint32_t)W));
+                    ia = (i0 - c0b) + s_rowbase;
+                } else {
+                    slot4 = (ms >> (META_SLOT_SHIFT - 2)) & 0xFCu;
+                    ia = __umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)A.cap) + i0 + s_rowbase;
+                }
                 const uint32_t x = i0 + (ms >> 21);
                 uint32_t q;
                 if ((uint32_t)T >= (uint32_t)(32 * W)) q = min(x - (uint32_t)T, x); /* x < 2T (wave-uniform test) */
@@ -532,7 +568,6 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
                  * Column: ib .. ib+4 on the forward strand; the reverse strand's weights are the forward ones mirrored
                  * (libgkm.c:924), bytes ib, ib-1, .., ib-4: fetched from ib-4 up and turned round by v_perm_b32 with
                  * strand-uniform selectors. */
-                const uint32_t ia = __umul24((ms >> META_PIECE_SHIFT) & 7u, (uint32_t)A.cap) + i0 + s_rowbase;
                 const uint32_t ib = (q ^ s_wsign) + s_wbase;      /* this window's byte */
                 const uint32_t il = ib - s_wback;                 /* the lowest of the five addresses (s_wback = 4 on the reverse strand) */
                 /* (ia, ib are LDS ADDRESSES here: s_rowbase and s_wbase include the dynamic LDS's start, below) */
@@ -540,7 +575,11 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
                 const lds_words pb = (lds_words)(uintptr_t)(il & ~3u);
                 const uint32_t a0 = pa[0], a1 = pa[1], b0 = pb[0], b1 = pb[1];
                 const uint32_t sha = (ia & 3u) << 3, shb = (il & 3u) << 3;
-                const uint32_t wa4 = __builtin_amdgcn_alignbit(a1, a0, sha), wa1 = a1 >> sha;
+                uint32_t wa4 = __builtin_amdgcn_alignbit(a1, a0, sha), wa1 = a1 >> sha;
+                if (PGROUP) { /* windows nv .. 4 of the group lie behind the row's last l-mer: weight 0 */
+                    wa4 &= 0xFFFFFFFFu >> (32u - 8u * min(nv, 4u));
+                    wa1 = nv >= 5u ? wa1 : 0u;
+                }
                 const uint32_t lo = __builtin_amdgcn_alignbit(b1, b0, shb), hi = b1 >> shb;
                 const uint32_t wb4 = __builtin_amdgcn_perm(hi, lo, s_perm4), wb1 = __builtin_amdgcn_perm(hi, lo, s_perm1);
                 /* (v_alignbit_b32 uses the low 5 bits of its count: 2 i0 mod 32 = 2 (i0 mod 16)) */
@@ -603,8 +642,8 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
             s_wback = strand ? 4u : 0u;
             s_perm4 = strand ? 0x01020304u : 0x03020100u;
             s_perm1 = strand ? 0x0c0c0c00u : 0x0c0c0c04u;
-            if (POSTAB) s_wbase = (uint32_t)pkw * 8u + POSTAB_PAD + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u) + /* ~q = -q - 1 */
-                                  (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u);
+            if (POSTAB || PGROUP) s_wbase = (uint32_t)pkw * 8u + POSTAB_PAD + (uint32_t)(L - 1) + (strand ? (uint32_t)nB : 0u) + /* ~q = -q - 1 */
+                                            (GROUP ? (uint32_t)(STATIC_WORDS * 4) : 0u);
             else s_wbase = (strand && !(nB & 1)) ? 1u : 0u;
             /* read-only, wave-uniform: address space 4 makes hipcc fetch these words with
              * scalar loads (s_load_dwordx*) into SGPRs instead of per-lane vector loads */

@@ -96,6 +96,8 @@ struct gkmhip_ctx {
     std::vector<double> h_cum_n; /* prefix sums of n_j = len_j - L + 1 */
     DevBuf<uint8_t> codes, wd; /* wd: distance-indexed positional weights */
     int wd_len = 0;
+    DevBuf<uint32_t> wdc; /* the same weights CENTRED (byte wdc_centre + s = wd[|s|]): the row side of the several-pieces group variants */
+    int wdc_words = 0, wdc_centre = 0;
     DevBuf<int64_t> off, lmoff;
     DevBuf<int> len;
     DevBuf<uint32_t> lmf, sb; /* lmf: forward l-mer table, then the reverse-strand table (general kernel only) */
