@@ -90,21 +90,19 @@ constexpr int BS_CAP = BS_TRIP + 64;
 template <int W, int L, int D, int PK>
 __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PACKED_WAVES) void k_gram_bitslice(const BsArgs A)
 {
-    /* PK = 0: one piece per lane, up to 64 rows per tile (every fixed-length data set);
-     *      1: several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
-     *      3: as 0, but a trip fetches the source lane's piece entry from that lane's registers (ds_bpermute_b32)
-     *         instead of a 512-byte table in LDS -- taken when those 512 bytes cost an LDS allocation granule,
-     *         i.e. waves per CU (rows and columns of 600 bp: 24 -> 32 one-wave workgroups per CU by LDS, 449 -> 436 ms
-     *         on gkmQC's defaults); where they do not, the table is 0.5 % faster (config 2: 76.7 vs 77.1 ms) */
+    /* PK = 4: problems whose sequences all have the same length (gkmQC's own 600-bp subsets, BASELINE configs 1-3);
+     *      1: everything else -- several pieces per lane (gkm_pack.h), up to 64 rows per tile; 2: up to 128 rows per tile;
+     *      0: one piece per lane, ragged lengths, piece entries in a 512-byte LDS table; 3: the same with the entries
+     *         fetched from the source lane's registers (ds_bpermute_b32) where those 512 bytes cost an LDS allocation
+     *         granule.  Since round 5 only for L < 5 and in the tests (GKM_NO_UNIF): with L >= 5 the variants 4, 1, 2
+     *         resolve hits by GROUPS (below), which beats both. */
     constexpr bool PACKED = PK == 1 || PK == 2;
     constexpr bool BPERM = PK == 3;
-    /*      4: as 0, for problems whose sequences all have the SAME length (every fixed-length data set: gkmQC's own
-     *         5 000 x 600 bp subsets, BASELINE configs 1-3): a row then takes k = ceil(windows / 311) whole lanes, piece
-     *         pi of it starts at sequence position pi * capacity, and all a trip needs of the source lane -- its row slot
-     *         and pi -- rides in the record's origin word (9 spare bits, set once per wave): no piece table, no permute,
-     *         and the row l-mer's weight comes from the column's own table by position (same length, same weights).
-     *         Round 5: an LDS operation in a trip costs what three VALU instructions do (sensitivity probes,
-     *         profiles/r5_trip_sensitivity.txt); this variant has two fewer than 3 and one LDS round trip less. */
+    /*      4: a row takes k = ceil(windows / 310) whole lanes, piece pi of it starts at sequence position pi * capacity,
+     *         and all a trip needs of the source lane -- its row slot and pi -- rides in the record's origin word (9 spare
+     *         bits, set once per wave): no piece table, no permute, and the row l-mer's weight comes from the column's own
+     *         table by position (same length, same weights).  Round 5: an LDS operation in a trip costs what three VALU
+     *         instructions do (sensitivity probes, profiles/r5_trip_sensitivity.txt). */
     constexpr bool UNIF = PK == 4;
     /* (The ablation builds of rounds 1-3 -- parts of this kernel skipped to time the rest, results wrong -- lived
      * here as a fifth template parameter; they are gone from the source since round 4.  tools/variants.sh rebuilds
@@ -115,15 +113,16 @@ __global__ __launch_bounds__(64, D > 4 ? 1 : PK == 4 ? GKM_BS_WAVES : GKM_BS_PAC
      * at accl + m * NSLOT + slot without testing m <= D; the windows with a larger m are the ones that wrap around the
      * end of the column strand, they carry the weight 0, and wherever m <= L lands it is inside this array):
      *   accl   [(D + 1) * NSLOT]     mismatch profiles [m][row slot]                              1-2.5 KB
-     *   s_list [(BS_GRP + 1) * CAP]  the hit list                                                 3 KB
-     *   lmask  [64]                  PACKED: piece-start bit rows of every lane                   0.25 KB
+     *   s_list [2 | BS_GRP + 1][CAP]  the hit list: two-word group records (GROUP), else five hit words + origin   1 | 3 KB
+     *   lmask  [64]                  PACKED without group records: piece-start bit rows of every lane   0.25 KB
      *   lpiece [64 * NP | 128 | 0]   piece entries (none in the BPERM variant)                    0-1 KB
      * DYNAMIC: the column's two 2-bit packed strands, interleaved word by word (2 * pkw words: 0.2 KB at 300 bp, 0.3 KB
-     * at 600 bp), then the column's positional weights by l-mer position with L - 1 zero bytes either side (T + L - 1
-     * bytes).  What the hit resolution reads per hit: two words of the column strand and one weight byte from LDS; two
-     * words of the row lane's packed positions (8 KB per tile -- 128 bytes per lane, of which 84 are used -- L1
-     * resident: the waves of a CU work on the same tile) and the row l-mer's weight byte (the 1-KB distance table)
-     * from global memory. */
+     * at 600 bp), then the weight tables: the column's weights by l-mer position (gkm_gram_bitslice.h POSTAB_PAD; ~T + L
+     * + 16 bytes), behind it the row side's -- none in the same-length variant (the rows read the column's table), the
+     * centred distance table in the several-pieces group variants, a copy of the distance table otherwise.  What a visit
+     * reads: two words of the column strand and the weight bytes from LDS; two words of the row lane's packed positions
+     * (8 KB per tile -- 128 bytes per lane, of which 84 are used -- L1 resident: the waves of a CU work on the same
+     * tile) from global memory. */
     extern __shared__ uint32_t s_dyn[];
     /* PACKED: lanes may hold several pieces (gkm_pack.h).  When no lane of the call holds more than one
      * piece (e.g. every fixed-length data set) the leaner variant runs: one (slot, centre) pair per lane.
