@@ -862,9 +862,11 @@ def run_rank(args, emit=None):
             else:
                 ctx.gram_rows(parts[c], out_ptr, n, None, 0, local, stream if on is None else on)
 
-        # Two side streams, chunks alternate between them: the kernel of chunk c+1 fills the CUs that the
-        # drain of chunk c leaves idle, and its all-gather overlaps as before.
-        side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if dist_on else None
+        # ONE side stream for the chunks' kernels (gkm_multi.hip compute_streams(): two launches on two streams run
+        # concurrently and complete together, so chunk c's all-gather would hide behind nothing); the collective runs on
+        # RCCL's own stream and overlaps the next chunk's kernel.  GKM_MULTI_STREAMS=two: rounds 2-5, for measurements.
+        nside = 2 if os.environ.get("GKM_MULTI_STREAMS") == "two" else 1
+        side = [torch.cuda.Stream(dev) for _ in range(nside)] if dist_on else None
 
         def step(probe=None):
             """probe: a dict that receives torch events around the collectives and the assembly (an extra,
@@ -876,8 +878,8 @@ def run_rank(args, emit=None):
             main_s = torch.cuda.current_stream()
             pending = []
             for c in range(chunks):
-                st = side[c & 1]
-                if c < 2:
+                st = side[c % nside]
+                if c < nside:
                     st.wait_stream(main_s)      # the previous step has finished reading slab / gathered
                 ctx.set_scratch_slot(c & 1)     # chunks c and c+2 share a slot and a stream
                 with torch.cuda.stream(st):
@@ -901,8 +903,8 @@ def run_rank(args, emit=None):
             ctx.set_scratch_slot(0)
             for w in pending:
                 w.wait()
-            main_s.wait_stream(side[0])
-            main_s.wait_stream(side[1])
+            for st in side:
+                main_s.wait_stream(st)
             if probe is not None:
                 probe["as0"] = torch.cuda.Event(enable_timing=True)
                 probe["as0"].record(main_s)

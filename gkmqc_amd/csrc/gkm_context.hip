@@ -524,6 +524,21 @@ extern "C" double gkmhip_kernel_timeline_ms(gkmhip_ctx *ctx, int *launches)
     return sum;
 }
 
+extern "C" int gkmhip_kernel_timeline_spans(gkmhip_ctx *ctx, double *out, int cap)
+{
+    if (!ctx || !out || (size_t)cap < 2 * ctx->tl_used) return 0;
+    for (size_t i = 0; i < ctx->tl_used; i++) {
+        float a = 0.f, b = 0.f;
+        if (hipEventSynchronize(ctx->tl_pairs[i].second) != hipSuccess ||
+            hipEventElapsedTime(&a, ctx->tl_pairs[0].first, ctx->tl_pairs[i].first) != hipSuccess ||
+            hipEventElapsedTime(&b, ctx->tl_pairs[0].first, ctx->tl_pairs[i].second) != hipSuccess)
+            return 0;
+        out[2 * i] = (double)a;
+        out[2 * i + 1] = (double)b;
+    }
+    return (int)(2 * ctx->tl_used);
+}
+
 extern "C" double gkmhip_last_kernel_ms(gkmhip_ctx *ctx)
 {
     if (!ctx || !ctx->ev_valid || !ctx->last_e1) return -1.0;

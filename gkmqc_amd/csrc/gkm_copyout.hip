@@ -50,6 +50,35 @@ __global__ void k_spin(long long ticks, unsigned *sink)
     if (ticks == 1234567) sink[0] = 1u;
 }
 
+/* Keeps `stream` busy for `microseconds` with ONE wave (k_spin): the multi-GPU path puts it in front of chunk c+1's launch
+ * so that the transfer of chunk c, which becomes runnable on another stream at the same moment, has its workgroups on the
+ * device before the Gram kernel takes every wave slot (gkm_multi.hip; tools/collective_beside_probe.py). */
+extern "C" int gkmhip_pause_stream(void *stream, int microseconds)
+{
+    if (microseconds <= 0) return 0;
+    if (microseconds > 10000) return set_err_msg("gkmhip_pause_stream: more than 10 ms", 2);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long)microseconds * 100, (unsigned *)nullptr); /* 100 MHz */
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* Measurement only (tools/collective_beside_probe.py): a device-to-device copy by `blocks` workgroups of `threads` threads,
+ * the launch shape of a collective's kernel (a few large, persistent workgroups), to see on ONE GPU whether such
+ * workgroups get onto the device while a Gram kernel holds every wave slot. */
+__global__ void k_probe_copy(uint4 *dst, const uint4 *src, size_t n16)
+{
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+
+extern "C" int gkmhip_probe_copy(void *dst, const void *src, size_t bytes, int blocks, int threads, void *stream)
+{
+    if (!dst || !src || blocks < 1 || threads < 64 || threads > 1024 || (bytes & 15)) return set_err_msg("gkmhip_probe_copy: bad arguments", 2);
+    hipLaunchKernelGGL(k_probe_copy, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream, (uint4 *)dst,
+                       (const uint4 *)src, bytes / 16);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 /* what the drop-in call's copy-out pipeline measured last time (gram_part_to_host_rows cuts its row blocks by it) */
 static struct {
     std::mutex m;
@@ -79,8 +108,26 @@ static bool runs_beside(hipStream_t busy, hipStream_t other, unsigned *d_word, u
 /* A new non-blocking stream on the current device that runs beside every stream of `busy` (see PipeStreams: streams
  * that share a hardware queue execute in order); after six candidates the last one is returned whatever it shares.
  * *beside says which it was. */
-extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *beside)
+/* CU mask that leaves `reserve` compute units to other streams, the same number in every XCD whichever way the mask's bits
+ * are numbered (XCD = bit / 32 or bit % 8): the j-th reserved CU of XCD k is bit 32 k + (k + 8 j) % 32.  A mask that takes
+ * its CUs from ONE XCD slows a machine-filling kernel by 50 % (its workgroups are dealt to the XCDs round robin:
+ * profiles/r4_overlap_probe.txt). */
+static std::vector<uint32_t> mask_reserving(int reserve)
 {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return {};
+    const int cus = prop.multiProcessorCount;
+    if (cus != 256 || reserve <= 0 || reserve % 8 || reserve > 32) return {}; /* (laid out for the MI355X's 8 x 32 CUs) */
+    std::vector<uint32_t> m((size_t)cus / 32, 0xFFFFFFFFu);
+    for (int j = 0; j < reserve / 8; j++)
+        for (int k = 0; k < 8; k++) m[(size_t)k] &= ~(1u << ((k + 8 * j) % 32));
+    return m;
+}
+
+static void *stream_beside(void *const *busy, int nbusy, int *beside, const int *priority, int reserve_cus = 0)
+{
+    const std::vector<uint32_t> cumask = mask_reserving(reserve_cus);
     unsigned *d_word = nullptr, *h_word = nullptr;
     if (hipMalloc((void **)&d_word, 2 * sizeof(unsigned)) != hipSuccess) return nullptr;
     if (hipHostMalloc((void **)&h_word, sizeof(unsigned), hipHostMallocPortable) != hipSuccess) {
@@ -92,7 +139,10 @@ extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *
     bool ok = false;
     for (int attempt = 0; attempt < 6 && !ok; attempt++) {
         hipStream_t c = nullptr;
-        if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+        const hipError_t e = !cumask.empty() ? hipExtStreamCreateWithCUMask(&c, (uint32_t)cumask.size(), cumask.data())
+                             : priority      ? hipStreamCreateWithPriority(&c, hipStreamNonBlocking, *priority)
+                                             : hipStreamCreateWithFlags(&c, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
         ok = true;
         for (int i = 0; i < nbusy && ok; i++) ok = runs_beside((hipStream_t)busy[i], c, d_word, h_word);
         if (ok || attempt == 5) got = c;
@@ -103,6 +153,22 @@ extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *
     (void)hipHostFree(h_word);
     if (beside) *beside = ok ? 1 : 0;
     return got;
+}
+
+extern "C" void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *beside)
+{
+    return stream_beside(busy, nbusy, beside, nullptr);
+}
+
+extern "C" void *gkmhip_create_stream_beside_prio(void *const *busy, int nbusy, int *beside, int priority)
+{
+    return stream_beside(busy, nbusy, beside, &priority);
+}
+
+extern "C" void *gkmhip_create_stream_reserving(void *const *busy, int nbusy, int *beside, int reserve_cus)
+{
+    if (mask_reserving(reserve_cus).empty()) return nullptr;
+    return stream_beside(busy, nbusy, beside, nullptr, reserve_cus);
 }
 
 /* The device's pair of streams, created and probed at the first call; the caller holds it until pipe_streams_done()

@@ -4,7 +4,7 @@
  *
  * Kernels
  *   k_build_rowplanes row-segment bit planes + the lanes' packed positions for one set of rows
- *   k_untile          tile-transposed values -> matrix rows (both sides in 512-byte runs)
+ *   k_untile          tile-transposed values -> matrix rows (128-byte lines in, 512-byte runs out; one-wave workgroups)
  *   k_gram_direct     general fallback: per-l-mer tables, l-mer by l-mer XOR/popcount (any L <= 12, d <= 12)
  * (k_gram_bitslice, the hot kernel: gkm_gram_bitslice.hip)
  */
@@ -55,33 +55,40 @@ __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64
     }
 }
 
-/* S (tile-transposed, see BsArgs) -> rows of G.  Block = 64 columns x 64 row slots of one tile, moved
- * through LDS so that both the reads (64 slots of one column) and the writes (64 columns of one row)
- * are 512-byte runs.  grid (column blocks, tiles * NSLOT / 64). */
+/* S (tile-transposed, see BsArgs) -> rows of G.  Block = 64 columns x UT_SLOTS row slots of one tile, moved through LDS
+ * so that the reads are whole 128-byte lines (16 slots of one column) and the writes 512-byte runs (64 columns of one
+ * row).  ONE wave and 8.5 KB of LDS per workgroup, on purpose: rounds 2-5 used 256 threads and 33 KB (64 x 64 values), and
+ * such a workgroup cannot START beside a Gram kernel -- whose 28 one-wave workgroups per CU leave 17-20 KB of LDS and no
+ * four free wave slots at one time -- so the untile of a multi-GPU rank's chunk c, on its own stream, ended when the Gram
+ * kernel of chunk c+1 did and the transfer of chunk c hid behind nothing (round 5, tools/rank_alone.py,
+ * profiles/r5_rank_alone_streams.txt).  grid (column blocks, tiles * NSLOT / UT_SLOTS). */
+constexpr int UT_SLOTS = 16;
 template <int NSLOT>
-__global__ __launch_bounds__(256) void k_untile(const double *__restrict__ S, const int64_t *__restrict__ tile_soff,
-                                                const int *__restrict__ tile_cbeg, const int *__restrict__ tile_cend,
-                                                const int *__restrict__ tile_nrows, const int *__restrict__ tile_row,
-                                                const int *__restrict__ tile_out, GramOut out)
+__global__ __launch_bounds__(64) void k_untile(const double *__restrict__ S, const int64_t *__restrict__ tile_soff,
+                                               const int *__restrict__ tile_cbeg, const int *__restrict__ tile_cend,
+                                               const int *__restrict__ tile_nrows, const int *__restrict__ tile_row,
+                                               const int *__restrict__ tile_out, GramOut out)
 {
-    __shared__ double buf[64][65];
-    const int tile = blockIdx.y / (NSLOT / 64), half = blockIdx.y % (NSLOT / 64);
+    __shared__ double buf[64][UT_SLOTS + 1];
+    constexpr int PARTS = NSLOT / UT_SLOTS;
+    const int tile = blockIdx.y / PARTS, part = blockIdx.y % PARTS;
     const int cbeg = tile_cbeg[tile], cend = tile_cend[tile], nrows = tile_nrows[tile];
     const int jb = cbeg + (int)blockIdx.x * 64;
-    if (jb >= cend || half * 64 >= nrows) return;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const double *src = S + (tile_soff[tile] + (jb - cbeg)) * NSLOT + half * 64;
-    for (int c = ty; c < 64; c += 4)
-        if (jb + c < cend && half * 64 + tx < nrows) buf[c][tx] = src[(int64_t)c * NSLOT + tx];
+    if (jb >= cend || part * UT_SLOTS >= nrows) return;
+    const int lane = threadIdx.x, ts = lane % UT_SLOTS, tc = lane / UT_SLOTS;
+    const double *src = S + (tile_soff[tile] + (jb - cbeg)) * NSLOT + part * UT_SLOTS;
+#pragma unroll 4
+    for (int c = tc; c < 64; c += 64 / UT_SLOTS)
+        if (jb + c < cend && part * UT_SLOTS + ts < nrows) buf[c][ts] = src[(int64_t)c * NSLOT + ts];
     __syncthreads();
-    for (int rl = ty; rl < 64; rl += 4) {
-        const int rs = half * 64 + rl;
+    const int j = jb + lane;
+    for (int rl = 0; rl < UT_SLOTS; rl++) {
+        const int rs = part * UT_SLOTS + rl;
         if (rs >= nrows) break;
         const int row = tile_row[tile * gkmpack::MAX_ROWS + rs];
-        const int j = jb + tx;
         if (j >= cend || (j > row && !out.write_all)) continue;
         const int64_t r = out.local_rows ? tile_out[tile * gkmpack::MAX_ROWS + rs] : row;
-        *gram_cell(out, r, j) = buf[tx][rl];
+        *gram_cell(out, r, j) = buf[lane][rl];
     }
 }
 
@@ -492,12 +499,12 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         if (out.G) {
             int span = 0;
             for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
-            const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / 64)));
+            const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / UT_SLOTS)));
             if (slots != 64)
-                hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
+                hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
                                    A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, A.out);
             else
-                hipLaunchKernelGGL(k_untile<64>, ug, dim3(256), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
+                hipLaunchKernelGGL(k_untile<64>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
                                    A.tile_nrows, A.tile_row, A.tile_out, A.out);
             HIPCHK(hipGetLastError());
         }

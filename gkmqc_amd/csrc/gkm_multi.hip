@@ -16,8 +16,8 @@
  *         or when RCCL cannot be loaded.  GKM_ALLGATHER=rccl|p2p forces one.
  * What travels are PACKED slabs (gkm_shard.h): row a as a + 1 doubles -- only j <= a is ever read -- n^2 / (2G)
  * doubles per rank and matrix, half of what full-width rows cost (round 3).
- * The chunks of a rank alternate between two compute streams; the transfer of chunk c runs on a
- * third stream and overlaps the kernel of chunk c+1.  Integer profiles are placement-independent,
+ * The chunks of a rank follow each other on ONE compute stream; the transfer of chunk c runs on a second stream and
+ * overlaps the kernel of chunk c+1 (compute_streams() below has the measurement that took the second compute stream away).  Integer profiles are placement-independent,
  * so the assembled matrix is bit-identical to the single-GPU one for any number of devices.
  */
 #include <hip/hip_runtime.h>
@@ -154,7 +154,7 @@ private:
  * ~1.7 GB and freed it again paid for that beside a ~10 ms kernel on 8 GPUs.  Keyed by (device, n, ranks, chunks);
  * rebuilt when any of them changes, freed by gkmhip_release_comms(). */
 struct RankCache {
-    int dev = -1, n = 0, G = 0, chunks = 0;
+    int dev = -1, n = 0, G = 0, chunks = 0, nsk = 0;
     int64_t pe = 0; /* doubles per (packed) chunk slab */
     double *slab = nullptr, *gathered = nullptr, *sq = nullptr;
     int64_t *d_slot = nullptr;
@@ -187,8 +187,22 @@ void cache_release(RankCache &R)
     R = RankCache();
 }
 
+/* How many compute streams a rank's chunk launches alternate between: ONE.  Rounds 2-5 used two ("the kernel of chunk c+1
+ * overlaps the drain of chunk c"), and round 5 measured what that does (tools/rank_alone.py prints when each chunk ran,
+ * profiles/r5_rank_alone_streams.txt): two launches on two streams run CONCURRENTLY, workgroup by workgroup, and complete
+ * together -- chunk 0 of 2 ended at 8.63 ms of a rank's 8.88 -- so nothing of chunk 0's transfer hid behind chunk 1's
+ * kernel, which is the only reason to cut a rank's rows into chunks.  (Stream priorities do not repair it: the
+ * higher-priority launch gets ~60 % of the device, and its small kernels that follow ended with the OTHER launch in
+ * most runs.)  On one stream chunk 0 is complete at 4.5 of 9.0 ms; the drain that is no longer overlapped costs 0.2-0.3 ms
+ * per chunk boundary.  GKM_MULTI_STREAMS=two brings the old behaviour back for measurements. */
+int compute_streams()
+{
+    const char *e = getenv("GKM_MULTI_STREAMS");
+    return (e && !strcmp(e, "two")) ? 2 : 1;
+}
+
 struct Call {
-    int G = 0, n = 0, chunks = 1, symmetric = 0;
+    int G = 0, n = 0, chunks = 1, symmetric = 0, nsk = 1;
     int64_t ld = 0, pe = 0;
     bool use_rccl = false;
     gkmhip_ctx **ctxs = nullptr;
@@ -206,7 +220,12 @@ struct Call {
 };
 
 /* what the most recent call measured, per rank (gkmhip_allgather_stats) */
-struct RankStats { double kernel_ms = 0, transfer_ms = 0, assemble_ms = 0, comparisons = 0; };
+struct RankStats {
+    double kernel_ms = 0, transfer_ms = 0, assemble_ms = 0, comparisons = 0;
+    /* per chunk: its launch group's start and end, its transfer's start and end, all counted from the start of the
+     * rank's first launch group (HIP event timestamps; gkmhip_allgather_chunk_times) */
+    std::vector<double> chunk_times;
+};
 std::vector<RankStats> g_stats;
 int g_stats_chunks = 0;
 long long g_bytes_per_rank = 0; /* received from the peers per matrix by every rank in the most recent call */
@@ -232,23 +251,26 @@ void rank_thread(Call &C, int g)
 
     /* ---- phase 0: buffers, streams, events (kept from the previous call of the same shape) ---- */
     MCHK(hipSetDevice(dev));
-    if (!fail && !(R.dev == dev && R.n == n && R.G == G && R.chunks == chunks && R.pe == C.pe)) {
+    if (!fail && !(R.dev == dev && R.n == n && R.G == G && R.chunks == chunks && R.pe == C.pe && R.nsk == C.nsk)) {
         cache_release(R);
-        R.dev = dev; R.n = n; R.G = G; R.chunks = chunks; R.pe = C.pe;
+        R.dev = dev; R.n = n; R.G = G; R.chunks = chunks; R.pe = C.pe; R.nsk = C.nsk;
         auto dmalloc = [&](void **p, size_t bytes) { g_allocs++; return hipMalloc(p, bytes); };
         MCHK(dmalloc((void **)&R.slab, (size_t)chunks * slab_elems * sizeof(double)));
         if (!fail) MCHK(dmalloc((void **)&R.gathered, (size_t)chunks * (size_t)G * slab_elems * sizeof(double)));
         if (!fail) MCHK(dmalloc((void **)&R.d_slot, (size_t)n * sizeof(int64_t)));
         if (!fail) MCHK(dmalloc((void **)&R.sq, (size_t)n * sizeof(double)));
-        /* the second compute stream and the transfer stream must not share a hardware queue with the first (streams
-         * on one queue execute in order: the all-gather of chunk c would wait for the kernel of chunk c+1) */
-        if (!fail) MCHK(hipStreamCreateWithFlags(&R.sk[0], hipStreamNonBlocking));
+        /* The transfer stream must not share a hardware queue with the compute stream (streams on one queue execute in
+         * order: the all-gather of chunk c would wait for the kernel of chunk c+1), so it is probed against it. */
+        void *busy[3] = {nullptr, nullptr, nullptr};
+        for (int i = 0; i < R.nsk && !fail; i++) {
+            if (i == 0) MCHK(hipStreamCreateWithFlags(&R.sk[0], hipStreamNonBlocking));
+            else R.sk[i] = (hipStream_t)gkmhip_create_stream_beside(busy, i, nullptr);
+            if (!fail && !R.sk[i]) { fail = true; C.err[(size_t)g] = "cannot create the rank's streams"; }
+            busy[i] = R.sk[i];
+        }
         if (!fail) {
-            void *busy[2] = {R.sk[0], nullptr};
-            R.sk[1] = (hipStream_t)gkmhip_create_stream_beside(busy, 1, nullptr);
-            busy[1] = R.sk[1];
-            if (R.sk[1]) R.sc = (hipStream_t)gkmhip_create_stream_beside(busy, 2, nullptr);
-            if (!R.sk[1] || !R.sc) { fail = true; C.err[(size_t)g] = "cannot create the rank's streams"; }
+            R.sc = (hipStream_t)gkmhip_create_stream_beside(busy, R.nsk, nullptr);
+            if (!R.sc) { fail = true; C.err[(size_t)g] = "cannot create the rank's streams"; }
         }
         R.ready.assign((size_t)chunks, nullptr);
         for (auto *v : {&R.k0, &R.k1, &R.a0, &R.a1}) v->assign((size_t)chunks, nullptr);
@@ -278,8 +300,15 @@ void rank_thread(Call &C, int g)
         const bool go = !C.failed.load();
         double *my_slab = go ? R.slab + (size_t)c * slab_elems : nullptr;
         if (go) {
-            hipStream_t st = sk[c & 1];
+            hipStream_t st = sk[c % R.nsk];
             const std::vector<int> &rows = parts[(size_t)c];
+            /* The transfer of chunk c - 1 becomes runnable (stream sc) when this launch group does, and it must be FIRST on
+             * the device: a collective's workgroups of 256-512 threads never start beside a running Gram kernel, which holds
+             * 7 of 8 wave slots and 504 of 512 VGPRs of every SIMD and replaces each wave that retires at once (round 5, one
+             * GPU, tools/collective_beside_probe.py: a 90-MB copy by 64 x 256 threads enqueued mid-kernel takes 5.3 ms
+             * instead of 0.10 and ends when the kernel does; one that waits for the previous kernel's event takes 0.19).
+             * What gives it the head start is this group's own table upload and row-plane kernel, ~0.1 ms in front of
+             * the Gram kernel: whoever moves them out of the way must put a pause here (gkmhip_pause_stream). */
             MCHK(hipEventRecord(R.k0[(size_t)c], st));
             if (!rows.empty()) {
                 const std::vector<int64_t> roff = gkmshard::packed_row_offsets(rows);
@@ -354,6 +383,8 @@ void rank_thread(Call &C, int g)
         for (int c = 0; c < chunks; c++) {
             if (hipEventElapsedTime(&ms, R.k0[(size_t)c], R.k1[(size_t)c]) == hipSuccess) st_out.kernel_ms += ms;
             if (hipEventElapsedTime(&ms, R.a0[(size_t)c], R.a1[(size_t)c]) == hipSuccess) st_out.transfer_ms += ms;
+            for (hipEvent_t ev : {R.k0[(size_t)c], R.k1[(size_t)c], R.a0[(size_t)c], R.a1[(size_t)c]})
+                st_out.chunk_times.push_back(hipEventElapsedTime(&ms, R.k0[0], ev) == hipSuccess ? (double)ms : -1.0);
         }
         if (hipEventElapsedTime(&ms, R.n0, R.n1) == hipSuccess) st_out.assemble_ms = ms;
         g_stats[(size_t)g] = st_out;
@@ -398,6 +429,18 @@ extern "C" int gkmhip_allgather_stats(double *out, int cap)
     return need;
 }
 
+/* out[4 c .. 4 c + 3] = chunk c of rank `rank` in the most recent call: launch group start / end, transfer start / end,
+ * ms from the start of the rank's first launch group.  Returns the number of doubles written. */
+extern "C" int gkmhip_allgather_chunk_times(int rank, double *out, int cap)
+{
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (!out || rank < 0 || (size_t)rank >= g_stats.size()) return 0;
+    const std::vector<double> &t = g_stats[(size_t)rank].chunk_times;
+    if ((size_t)cap < t.size()) return 0;
+    for (size_t i = 0; i < t.size(); i++) out[i] = t[i];
+    return (int)t.size();
+}
+
 /* ONE rank of a `ranks`-way gkmhip_gram_allgather, alone on its device: what a rank's step costs without the transfer.
  * No node with several GPUs has been available to any round, and a rehearsal with all ranks on one device makes every
  * rank's kernel `ranks` times too long; this runs rank `rank`'s own chunks (same layout, streams, scratch slots, packed
@@ -418,7 +461,8 @@ extern "C" int gkmhip_gram_rank_alone(gkmhip_ctx *ctx, int rank, int ranks, int 
     C.chunks = ranks == 1 ? 1 : (chunks > 0 ? chunks : gkmshard::auto_chunks(C.n, ranks));
     C.pe = gkmshard::packed_chunk_elems(C.n, ranks, C.chunks);
     const RankCache &R = g_cache[rank];
-    if (!(R.dev == gkmhip_device_of(ctx) && R.n == C.n && R.G == ranks && R.chunks == C.chunks && R.pe == C.pe))
+    C.nsk = compute_streams();
+    if (!(R.dev == gkmhip_device_of(ctx) && R.n == C.n && R.G == ranks && R.chunks == C.chunks && R.pe == C.pe && R.nsk == C.nsk))
         return fail_with("gkmhip_gram_rank_alone: no gathered slabs of this shape (run gkmhip_gram_allgather with the same "
                          "number of contexts and chunks first)", 2);
     std::vector<gkmhip_ctx *> ctxs((size_t)ranks, nullptr);
@@ -459,6 +503,7 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
     C.K = K;
     C.ld = ld;
     C.symmetric = symmetric;
+    C.nsk = compute_streams();
     C.n = gkmhip_n_sequences(ctxs[0]);
     bool distinct = true;
     for (int g = 0; g < nctx; g++) {

@@ -144,6 +144,15 @@ def load():
         L.gkmhip_gram_rank_alone.argtypes = (vp, i32, i32, i32, vp, i64, i32, vp)
     L.gkmhip_last_transport.restype = ctypes.c_char_p
     L.gkmhip_release_comms.restype = None
+    if hasattr(L, "gkmhip_probe_copy"):
+        L.gkmhip_probe_copy.restype = i32
+        L.gkmhip_probe_copy.argtypes = (vp, vp, ctypes.c_size_t, i32, i32, vp)
+    if hasattr(L, "gkmhip_kernel_timeline_spans"):
+        L.gkmhip_kernel_timeline_spans.restype = i32
+        L.gkmhip_kernel_timeline_spans.argtypes = (vp, vp, i32)
+    if hasattr(L, "gkmhip_allgather_chunk_times"):
+        L.gkmhip_allgather_chunk_times.restype = i32
+        L.gkmhip_allgather_chunk_times.argtypes = (i32, vp, i32)
     if hasattr(L, "gkmhip_allgather_stats"):   # (older builds loaded through GKM_LIB_PATH for A/B timing lack them)
         L.gkmhip_allgather_alloc_count.restype = ctypes.c_long
         L.gkmhip_allgather_stats.restype = i32

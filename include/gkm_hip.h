@@ -179,6 +179,12 @@ long long gkmhip_allgather_bytes_per_rank(void);
  * {kernel ms summed over its chunks, transfer ms summed over its chunks, un-permute + normalise ms, l-mer
  * comparisons of its rows}.  Returns the number of doubles written, 0 if `cap` is too small or nothing ran. */
 int gkmhip_allgather_stats(double *out, int cap);
+/* WHEN the chunks of rank `rank` ran in the most recent gkmhip_gram_allgather / gkmhip_gram_rank_alone: for every chunk
+ * c, out[4c .. 4c+3] = start and end of its launch group (tables, row planes, Gram kernel, untile) and start and end of
+ * its transfer, in ms from the start of the rank's first launch group (HIP event timestamps).  The transfer of chunk c
+ * can only hide behind the kernel of chunk c + 1 if chunk c ENDS well before chunk c + 1 does.  Returns the number of
+ * doubles written, 0 if `cap` is too small or nothing ran. */
+int gkmhip_allgather_chunk_times(int rank, double *out, int cap);
 
 /* Un-permutation + normalisation in one pass: matrix row a is row slot_of_row[a] (device array, n
  * int64) of `slabs` (device, leading dimension lds >= n, raw values); with lds == 1 slot_of_row[a] is the
@@ -193,6 +199,20 @@ int gkmhip_assemble_normalize(gkmhip_ctx *ctx, const double *slabs, int64_t lds,
  * candidate is tried with a 2-ms spin kernel on the busy stream and a 4-byte copy on the candidate; after six
  * candidates the last one is returned anyway (*beside = 0).  NULL on error.  Destroy it with hipStreamDestroy. */
 void *gkmhip_create_stream_beside(void *const *busy, int nbusy, int *beside);
+/* The same with a stream priority (hipStreamCreateWithPriority; hipDeviceGetStreamPriorityRange gives the range, the
+ * numerically LOWEST value is the highest priority). */
+void *gkmhip_create_stream_beside_prio(void *const *busy, int nbusy, int *beside, int priority);
+/* A compute stream that leaves `reserve_cus` (8, 16, 24 or 32: the same number in each of the MI355X's 8 XCDs) compute
+ * units to OTHER streams (hipExtStreamCreateWithCUMask).  Why: a workgroup of several waves -- a collective's kernel, a
+ * blit copy -- cannot start while the Gram kernel holds 7 of 8 wave slots and 504 of 512 VGPRs of every SIMD (each wave
+ * that retires is replaced by the kernel's next one-wave workgroup at once); enqueued mid-kernel on a high-priority stream
+ * it ends when the kernel does (tools/collective_beside_probe.py).  NULL if the device is not laid out as 8 x 32 CUs. */
+void *gkmhip_create_stream_reserving(void *const *busy, int nbusy, int *beside, int reserve_cus);
+/* Keeps `stream` busy for `microseconds` (at most 10 000) with one wave that does nothing. */
+int gkmhip_pause_stream(void *stream, int microseconds);
+/* Measurement only: copies `bytes` (a multiple of 16) on the device with `blocks` workgroups of `threads` threads on
+ * `stream` -- the launch shape of a collective's kernel (tools/collective_beside_probe.py). */
+int gkmhip_probe_copy(void *dst, const void *src, size_t bytes, int blocks, int threads, void *stream);
 
 /* The pinned staging buffers of the copy-out calls (2 x 64 MB) are kept for the life of the
  * process; this releases them (optional). */
@@ -206,6 +226,9 @@ double gkmhip_last_kernel_ms(gkmhip_ctx *ctx);
  * the sum of the Gram kernels' durations since the last switch-on (*launches = how many), <0 on failure. */
 int gkmhip_kernel_timeline(gkmhip_ctx *ctx, int on);
 double gkmhip_kernel_timeline_ms(gkmhip_ctx *ctx, int *launches);
+/* ... and WHEN they ran: out[2i], out[2i+1] = start and end of the i-th Gram kernel since the switch-on, in ms from the
+ * start of the first (launches on different streams may overlap).  Returns the number of doubles written. */
+int gkmhip_kernel_timeline_spans(gkmhip_ctx *ctx, double *out, int cap);
 /* number of l-mer comparisons that call evaluated (algorithmic: 2 n_a n_j per pair) */
 double gkmhip_last_comparisons(gkmhip_ctx *ctx);
 const char *gkmhip_last_kernel_name(gkmhip_ctx *ctx);

@@ -654,6 +654,13 @@ def test_one_rank_alone_reassembles_the_matrix(dev, nctx, chunks):
             assert rc == 0, lib.gkmhip_last_error().decode()
             assert torch.equal(Ks[g], one), "rank %d alone" % g
             assert out6[0] > 0 and out6[1] > 0 and out6[3] > 0 and out6[4] > 0 and int(out6[5]) >= 2
+            # the chunks of a rank follow each other on ONE compute stream (gkm_multi.hip compute_streams()): chunk c is
+            # complete before chunk c + 1 starts, or its transfer could hide behind nothing
+            ct = np.zeros(4 * 16)
+            nct = lib.gkmhip_allgather_chunk_times(g, ct.ctypes.data, len(ct))
+            assert nct == 4 * int(out6[5])
+            ct = ct[:nct].reshape(-1, 4)
+            assert (ct[:-1, 1] <= ct[1:, 0] + 1e-3).all() and (ct[:, 0] <= ct[:, 1]).all(), ct
     finally:
         for c in ctxs:
             c.close()

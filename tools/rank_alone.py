@@ -84,7 +84,7 @@ def main():
                "allgather_parity_ok": par.get("ok"), "ranks": {}}
         out6 = np.zeros(6)
         for g in range(G):
-            rows = []
+            rows, times, spans = [], [], []
             for rep in range(args.reps + 1):
                 Ks[g].zero_()
                 torch.cuda.synchronize(dev)
@@ -93,19 +93,30 @@ def main():
                 if rc:
                     raise SystemExit("gkmhip_gram_rank_alone failed: " + lib.gkmhip_last_error().decode())
                 gram, launches = ctxs[g].kernel_timeline_ms()
+                sp = np.zeros(2 * 16)
+                nsp = lib.gkmhip_kernel_timeline_spans(ctxs[g].handle, sp.ctypes.data, len(sp)) if hasattr(lib, "gkmhip_kernel_timeline_spans") else 0
                 ctxs[g].kernel_timeline(False)
+                ct = np.zeros(4 * 16)
+                nct = lib.gkmhip_allgather_chunk_times(g, ct.ctypes.data, len(ct)) if hasattr(lib, "gkmhip_allgather_chunk_times") else 0
                 if rep:
                     rows.append((out6[0], out6[1], gram, out6[2], out6[3], launches))
+                    times.append(ct[:nct].reshape(-1, 4).copy())
+                    spans.append(sp[:nsp].reshape(-1, 2).copy())
             ok = bench.parity_of_device_matrix(a, Ks[g]).get("ok")
             arr = np.array(rows)
             best = arr[arr[:, 0].argmin()]
             per["ranks"][g] = {"wall_ms_min": float(arr[:, 0].min()), "wall_ms_median": float(np.median(arr[:, 0])),
                                "kernels_ms": float(best[1]), "gram_ms": float(best[2]), "copy_in_ms": float(best[3]),
                                "assemble_ms": float(best[4]), "launches": int(best[5]), "comparisons": float(out6[4]),
-                               "parity_ok": ok}
+                               "parity_ok": ok,
+                               "chunk_launch_group_start_end_ms": times[int(arr[:, 0].argmin())][:, :2].tolist(),
+                               "chunk_slab_copy_start_end_ms": times[int(arr[:, 0].argmin())][:, 2:].tolist(),
+                               "gram_kernel_start_end_ms": spans[int(arr[:, 0].argmin())].tolist()}
             print("G=%d rank %d: wall %.2f ms (median %.2f), launch groups %.2f, Gram kernels %.2f (%d launches), copy-in %.2f, "
-                  "assemble %.2f; ideal %.2f (one-GPU kernel / G); matrix %s"
-                  % (G, g, arr[:, 0].min(), np.median(arr[:, 0]), best[1], best[2], best[5], best[3], best[4], kern1 / G,
+                  "assemble %.2f; chunks ran %s ms (their Gram kernels %s); ideal %.2f (one-GPU kernel / G); matrix %s"
+                  % (G, g, arr[:, 0].min(), np.median(arr[:, 0]), best[1], best[2], best[5], best[3], best[4],
+                     ", ".join("%.2f-%.2f (its slab copied %.2f-%.2f)" % tuple(x) for x in times[int(arr[:, 0].argmin())]),
+                     ", ".join("%.2f-%.2f" % (x[0], x[1]) for x in spans[int(arr[:, 0].argmin())]), kern1 / G,
                      "identical to the reference's" if ok else "NOT CHECKED" if ok is None else "WRONG"), flush=True)
         walls = [v["wall_ms_min"] for v in per["ranks"].values()]
         per["max_wall_ms"] = max(walls)
