@@ -259,14 +259,12 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
          * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
         /* (a jump in the row list -- a multi-GPU rank's two folded row blocks -- closes the tile where that means fewer
          * work items: gkm_pack.h) */
-        /* same-length problems (the same-length kernel variant, PK = 4, evaluates groups of five lane positions at once:
-         * full lanes own a multiple of five windows; L >= 5: the zero bytes behind its weight table must cover a group) */
+        /* Every variant resolves hits by GROUPS of five lane positions (k_gram_bitslice): a piece that does not finish
+         * its row owns a multiple of five windows.  Same-length problems take the variant that needs neither piece table nor
+         * permute (PK = 4); GKM_FORCE_PACKED=1|128 (tests, A/B runs) puts them on the several-pieces variants. */
         const bool same_length = ctx->minlen == ctx->maxlen;
-        const bool want_unif = same_length && L >= 5 && getenv("GKM_NO_UNIF") == nullptr && getenv("GKM_FORCE_PACKED") == nullptr &&
-                               gkm_pick_bitslice(4, L, d) != nullptr;
-        /* every bit-sliced variant with L >= 5 resolves hits by GROUPS of five lane positions (k_gram_bitslice GROUP): a
-         * piece that does not finish its row owns a multiple of five windows */
-        const int own_mult = L >= 5 ? 5 : 1;
+        const bool unif = same_length && getenv("GKM_FORCE_PACKED") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
+        const int own_mult = 5;
         auto pack = [&](int max_rows) {
             gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, 0, own_mult);
             if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
@@ -284,45 +282,23 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             }
         }
         const int W = pk.W, ntiles = pk.ntiles;
-        /* no lane with a second piece -> the leaner kernel variant */
-        bool packed = getenv("GKM_FORCE_PACKED") != nullptr || slots != 64;
+        /* everything but a same-length problem whose rows fill whole lanes -- ragged one-piece data too -- takes the
+         * several-pieces variants */
+        bool packed = !unif || slots != 64;
         for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
-        /* one piece per lane but ragged lengths: the several-pieces variant serves them too, and with L >= 5 it resolves
-         * hits by groups, which the table / permute variants (PK = 0, 3) do not */
-        if (!packed && !want_unif && L >= 5 && getenv("GKM_NO_UNIF") == nullptr) packed = true;
-        const bool pgroup = packed && L >= 5;
         const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
-        bs_kernel_t bs = !packed ? gkm_pick_bitslice(0, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
+        bs_kernel_t bs = !packed ? gkm_pick_bitslice(4, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
         /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
         if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream)) return 4;
         /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
          * kernel depend on its occupancy? */
         const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
-        /* dynamic LDS of a wave: the column's two packed strands + the weight bytes.  One-piece variants: the column's
-         * weights by position with zeros either side (ctx->ptw words, k_gram_bitslice POSTAB), and behind them a copy of
-         * the distance table for the row side unless every sequence has the same length (PK = 4: the rows read the
-         * column's table by position); several-pieces variants: the distance table alone. */
-        const size_t wd_bytes = (size_t)((ctx->wd_len + 3) / 4) * 4;
+        /* dynamic LDS of a wave: the column's two packed strands + the column's weights by position with zeros either side
+         * (ctx->ptw words) + the centred distance table for the row side in the several-pieces variants (the same-length
+         * variant's rows read the column's table by position) */
         const size_t postab_bytes = (size_t)ctx->ptw * 4;
-        /* same-length problems, one piece per lane: the variant that needs neither piece table nor permute (PK = 4) */
-        const bool unif = !packed && want_unif;
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad +
-                               (pgroup ? postab_bytes + (size_t)ctx->wdc_words * 4 : packed ? wd_bytes : postab_bytes + (unif ? 0 : wd_bytes));
+        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad + postab_bytes + (packed ? (size_t)ctx->wdc_words * 4 : 0);
         static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
-        if (unif) bs = gkm_pick_bitslice(4, L, d);
-        bool bperm = false;
-        if (!packed && !unif) { /* the variant without the piece table in LDS, where that saves an LDS allocation granule */
-            hipFuncAttributes fa, fb;
-            const char *force = getenv("GKM_FORCE_BPERM");
-            bs_kernel_t bsp = gkm_pick_bitslice(3, L, d);
-            auto granules = [](size_t bytes) { return (bytes + 1279) / 1280; };
-            if (force ? atoi(force) != 0
-                      : (hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess &&
-                         hipFuncGetAttributes(&fb, (const void *)bsp) == hipSuccess &&
-                         granules(fa.sharedSizeBytes + dyn_lds) > granules(fb.sharedSizeBytes + dyn_lds)))
-                bperm = true;
-            if (bperm) bs = bsp;
-        }
         auto nwin_of = [&](int row) { return ctx->h_len[(size_t)row] - L + 1; };
         const size_t nl = (size_t)ntiles * 64;
         std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
@@ -341,12 +317,10 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
             const bool second = 2 * pk.tile_nrows[(size_t)tile_of] <= slots && (pc.lane & 1);
             const uint32_t slot4 = ((uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u)) * 4u;
             const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
-            if (pgroup) { /* slot | centre offset << 7 | owned windows << 20 (k_gram_bitslice PGROUP) */
+            if (packed) { /* slot | centre offset << 7 | owned windows << 20 (k_gram_bitslice) */
                 if (slot4 / 4 > 127 || c0b > 0x1FFFu || pc.cnt > 511) return set_err_msg("gram: piece entry out of range", 2);
                 lane_piece[(size_t)pc.lane * NP + k] = (slot4 / 4u) | (c0b << 7) | ((uint32_t)pc.cnt << 20);
-            } else if (packed) {
-                lane_piece[(size_t)pc.lane * NP + k] = slot4 | (c0b << 16);
-            } else if (unif) {
+            } else {
                 /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index
                  * is the piece's first position over the lane capacity: pieces of a same-length problem fill whole lanes */
                 const int cap = gkmbs::segment_capacity(W, L) / 5 * 5; /* (own_mult = 5) */
@@ -354,9 +328,6 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                     return set_err_msg("gram: same-length packing broke its own rule", 2);
                 lane_piece[(size_t)pc.lane * 2] = ((slot4 / 4u) << gkmbs::META_SLOT_SHIFT) |
                                                   ((uint32_t)(pc.p0 / cap) << gkmbs::META_PIECE_SHIFT);
-            } else {
-                lane_piece[(size_t)pc.lane * 2] = slot4;
-                lane_piece[(size_t)pc.lane * 2 + 1] = c0b;
             }
         }
         /* columns [cbeg, cend) per tile */
@@ -470,8 +441,8 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
         A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
         A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
-        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p; A.wd8 = ctx->wd.p;
-        A.rpw = rpw; A.pkw = ctx->pkw; A.wd_words = (ctx->wd_len + 3) / 4; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
+        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p;
+        A.rpw = rpw; A.pkw = ctx->pkw; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
         A.cap = gkmbs::segment_capacity(W, L) / 5 * 5;
         A.wdc = ctx->wdc.p; A.wdc_words = ctx->wdc_words; A.wdc_centre = ctx->wdc_centre;
         A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
@@ -516,7 +487,7 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
                 fprintf(stderr, "gkmhip: hot kernel: %d VGPRs, %zu + %zu bytes of LDS per wave, %d one-wave workgroups per CU\n",
                         fa.numRegs, (size_t)fa.sharedSizeBytes, dyn_lds, per_cu);
         }
-        ctx->last_kernel = unif ? "k_gram_bitslice<same length>" : bperm ? "k_gram_bitslice<bperm>" : !packed ? "k_gram_bitslice" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+        ctx->last_kernel = !packed ? "k_gram_bitslice<same length>" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
     } else {
         if (ensure_lmers(ctx, stream)) return 4;
         if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;

@@ -10,15 +10,16 @@
 struct BsArgs {
     const uint32_t *rowplanes;  /* [tile][plane 3][W][64] */
     const uint32_t *lane_mask;  /* [tile*64] bit rows at which a piece starts */
-    const uint32_t *lane_piece; /* [tile*64][MAX_PIECES][2]: row slot, l-mer table base of the piece */
+    const uint32_t *lane_piece; /* several pieces: [tile*64][MAX_PIECES] row slot | centre offset << 7 | owned windows << 20;
+                                 * same length: [tile*64][2], word 0 = row slot and piece index as the origin word holds them */
     const int *tile_row, *tile_out, *tile_nrows, *tile_cbeg, *tile_cend; /* columns [cbeg, cend) per tile */
     const uint32_t *rowpk;      /* [tile*64 + lane][rpw] the lanes' positions, 2-bit packed (k_build_rowplanes) */
     const uint32_t *colpk;      /* [seq][pkw][strand] 2-bit packed strands, the two strands interleaved        */
-    const uint8_t *wd8;         /* distance-indexed positional weights wd[|n/2 - p|], WD_LDS bytes (ones if unweighted) */
-    int rpw, pkw, wd_words;     /* wd_words: dwords of wd8 that hold weights (the kernels copy that many to LDS) */
-    const uint32_t *postab;     /* [seq][ptw] every sequence's weights BY POSITION, L - 1 zero bytes either side (k_build_postab):
-                                 * what the one-piece variants keep in LDS for the column (k_gram_bitslice POSTAB) */
-    const uint32_t *wdc;        /* several-pieces group variants: the distance weights CENTRED, byte wdc_centre + s = wd[|s|] */
+    int rpw, pkw;               /* words per lane of rowpk (32: 128 bytes); words per strand of colpk */
+    const uint32_t *postab;     /* [seq][ptw] every sequence's weights BY POSITION, L - 1 zero bytes either side and five wrap
+                                 * bytes outside those (k_build_postab; POSTAB_PAD below): the column's weights in LDS */
+    const uint32_t *wdc;        /* several-pieces variants: the distance weights CENTRED, byte wdc_centre + s = wd[|s|] (the
+                                 * row side's weights) */
     int wdc_words, wdc_centre;
     int cap;                    /* same-length variant: l-mer windows a full lane owns (a multiple of 5: gkm_pack.h own_mult) */
     int ptw, ptw_stride;        /* ptw_stride = ptw, or 0 when every sequence has the same length: one table, which then stays

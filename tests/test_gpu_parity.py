@@ -303,7 +303,7 @@ def test_int32_wraparound_matches_wrapping_arithmetic(dev):
         assert (res["P"].cpu().numpy()[il] == want[il]).all()
 
 
-ALL_LD = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)] + [(11, 5), (12, 5), (12, 6)]
+ALL_LD = [(L, d) for L in range(5, 13) for d in range(0, 5)] + [(11, 5), (12, 5), (12, 6)]
 
 
 @pytest.mark.parametrize("L,d", ALL_LD)
@@ -393,45 +393,41 @@ def test_packed_variants_on_fixed_length_data(dev, monkeypatch):
         assert helpers.max_rel_err(helpers.tril_pack(res["K"].cpu().numpy()), z["c2_cut192_K"]) < K_TOL
 
 
-def test_piece_entries_from_lds_or_by_permute(dev, monkeypatch):
-    """One piece per lane, three ways for a trip to learn the source lane's row slot and weight offset: from the record's
-    origin word itself where every sequence has the same length (the default there, round 5: no table, no permute), from a
-    512-byte LDS table, or from the source lane's registers (ds_bpermute) where that table would cost an LDS allocation
-    granule.  The latter two serve ragged one-piece data; here they are forced (GKM_NO_UNIF) onto 300-bp rows (one lane
-    each) and 600-bp rows (two lanes each) so that all three see the same fixtures, bit for bit."""
+def test_same_length_and_ragged_one_piece_rows(dev, monkeypatch):
+    """Where every sequence has the same length a trip learns the source lane's row slot and piece index from the record's
+    origin word itself (no table, no permute: `<same length>`), on 300-bp rows (one lane each) and 600-bp rows (two lanes
+    each); ragged lengths that still take one lane per row go to the several-pieces variant, which serves every other
+    shape.  Word lengths below 5 have no bit-sliced kernel (a group of five windows must fit the zero bytes either side
+    of a weight table): `auto` takes the general kernel there and an explicit request is refused."""
     z = helpers.synthetic_expected()
     seqs = helpers.synth_codes(192, 192, 300)
     il = np.tril_indices(len(seqs))
     long_rows = helpers.synth_codes(70, 70, 600)
     want = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
     il2 = np.tril_indices(len(long_rows))
-
-    def check(name):
-        res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
-        assert res["kernel"] == name
-        assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
-        res = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
-        assert res["kernel"] == name
-        assert (res["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
-        assert (res["K"].cpu().numpy() == want["K"].cpu().numpy()).all()
-
-    check("k_gram_bitslice<same length>")
-    monkeypatch.setenv("GKM_NO_UNIF", "1")
-    assert dev.gram_matrix(seqs, 4, 11, 7, 3, kernel=dev.KERNEL_BITSLICE)["kernel"] in ("k_gram_bitslice", "k_gram_bitslice<bperm>")
-    for forced, name in (("1", "k_gram_bitslice<bperm>"), ("0", "k_gram_bitslice")):
-        monkeypatch.setenv("GKM_FORCE_BPERM", forced)
-        check(name)
-    monkeypatch.delenv("GKM_FORCE_BPERM")
-    monkeypatch.delenv("GKM_NO_UNIF")
-    # ragged lengths that still take one lane per row: with L >= 5 the several-pieces variant serves them (it resolves hits
-    # by groups; round 5), with L < 5 the table / permute variants
+    res = dev.gram_matrix(seqs, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    assert res["kernel"] == "k_gram_bitslice<same length>"
+    assert (res["P"].cpu().numpy()[il] == z["c2_cut192_P"][il]).all()
+    res = dev.gram_matrix(long_rows, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    assert res["kernel"] == "k_gram_bitslice<same length>"
+    assert (res["P"].cpu().numpy()[il2] == want["P"].cpu().numpy()[il2]).all()
+    assert (res["K"].cpu().numpy() == want["K"].cpu().numpy()).all()
     ragged = helpers.synth_codes(100, 100, 300, (305, 320))
     il3 = np.tril_indices(len(ragged))
-    for (L, k, d, names) in ((11, 7, 3, ("k_gram_bitslice<packed>",)), (4, 2, 2, ("k_gram_bitslice", "k_gram_bitslice<bperm>"))):
-        r = dev.gram_matrix(ragged, 4, L, k, d, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
-        w = dev.gram_matrix(ragged, 4, L, k, d, want_profiles=True, kernel=dev.KERNEL_DIRECT)
-        assert r["kernel"] in names, r["kernel"]
-        assert (r["P"].cpu().numpy()[il3] == w["P"].cpu().numpy()[il3]).all() and (r["K"].cpu().numpy() == w["K"].cpu().numpy()).all()
+    r = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    w = dev.gram_matrix(ragged, 4, 11, 7, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    assert r["kernel"] == "k_gram_bitslice<packed>"
+    assert (r["P"].cpu().numpy()[il3] == w["P"].cpu().numpy()[il3]).all() and (r["K"].cpu().numpy() == w["K"].cpu().numpy()).all()
+    # same-length rows short enough for two per lane: several pieces per lane, so not the same-length variant
+    short = helpers.synth_codes(150, 150, 140)
+    r = dev.gram_matrix(short, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_BITSLICE)
+    w = dev.gram_matrix(short, 4, 10, 6, 3, want_profiles=True, kernel=dev.KERNEL_DIRECT)
+    il4 = np.tril_indices(len(short))
+    assert r["kernel"].startswith("k_gram_bitslice<packed")
+    assert (r["P"].cpu().numpy()[il4] == w["P"].cpu().numpy()[il4]).all() and (r["K"].cpu().numpy() == w["K"].cpu().numpy()).all()
+    assert dev.gram_matrix(ragged, 4, 4, 2, 2)["kernel"] == "k_gram_direct"
+    with pytest.raises(dev.GkmError, match="not instantiated"):
+        dev.gram_matrix(ragged, 4, 4, 2, 2, kernel=dev.KERNEL_BITSLICE)
 
 
 def test_reused_context_with_longer_second_subset(dev):

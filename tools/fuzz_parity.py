@@ -13,7 +13,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-BITSLICED = [(L, d) for L in range(3, 13) for d in range(0, min(4, L - 1) + 1)]   # all have a bit-sliced kernel
+BITSLICED = [(L, d) for L in range(5, 13) for d in range(0, 5)]   # all have a bit-sliced kernel
 
 
 def main():
