@@ -224,9 +224,311 @@ bool bitslice_serves(const gkmhip_ctx *ctx)
 }
 
 
-/* One launch of the Gram kernel for a set of rows.  mode says which columns every tile of rows
- * visits: COLS_TRIANGLE j <= largest row of the tile (the path of gkm_main_pywrapper),
- * COLS_FULL every sequence, COLS_DIAGONAL only the band of the tile's own rows (self norms). */
+/* ---- the bit-sliced launch, host side: what a launch needs that depends on the rows and not on the device ---- */
+struct BitslicePlan {
+    gkmpack::Packing pk;              /* rows -> lanes (gkm_pack.h) */
+    int slots = 64;                   /* row slots per tile: 64 or 128 */
+    bool packed = false, same_length = false;
+    bs_kernel_t kernel = nullptr;
+    const char *name = "";
+    size_t dyn_lds = 0;
+    std::vector<int> desc;            /* [lane][piece][5] row, b0, nb, p0, cnt: what k_build_rowplanes reads */
+    std::vector<uint32_t> lane_mask, lane_piece;
+    std::vector<int> cbeg, cend;      /* columns [cbeg, cend) per tile */
+    std::vector<int64_t> soff;        /* first work item of each tile in the plain order; soff[ntiles] = items */
+    std::vector<int64_t> ent_off;     /* (column chunk, tile) entries: the other order of the work items (BsArgs) */
+    std::vector<int> ent_tile, ent_j0, ent_j1;
+    int64_t n_items = 0;
+};
+
+/* Pack the rows, choose the kernel variant, fill the per-lane tables, the tiles' column ranges and the work-item order.
+ * mode says which columns every tile of rows visits: COLS_TRIANGLE j <= largest row of the tile (the path of
+ * gkm_main_pywrapper), COLS_FULL every sequence, COLS_DIAGONAL only the band of the tile's own rows (self norms). */
+static int plan_bitslice(const gkmhip_ctx *ctx, const int *rows, int nrows, int mode, BitslicePlan &P)
+{
+    const int L = ctx->L, d = ctx->d, n = ctx->n;
+    std::vector<int> nwin((size_t)nrows);
+    for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
+    /* Every variant resolves hits by GROUPS of five lane positions (k_gram_bitslice): a piece that does not finish its row
+     * owns a multiple of five windows.  Same-length problems take the variant that needs neither piece table nor permute
+     * (PK = 4); GKM_FORCE_PACKED=1|128 (tests, A/B runs) puts them on the several-pieces variants. */
+    P.same_length = ctx->minlen == ctx->maxlen;
+    const bool unif = P.same_length && getenv("GKM_FORCE_PACKED") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
+    const int own_mult = 5;
+    /* (a jump in the row list -- a multi-GPU rank's two folded row blocks -- closes the tile where that means fewer work
+     * items: gkm_pack.h) */
+    auto pack = [&](int max_rows) {
+        gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, 0, own_mult);
+        if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
+        gkmpack::Packing b = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, gkmpack::LANES, own_mult);
+        return gkmpack::triangle_items(b) < gkmpack::triangle_items(a) ? b : a;
+    };
+    /* At most 64 rows per tile unless that leaves lanes empty (rows shorter than half a lane): the 64-slot kernels keep a
+     * wave more per SIMD (k_gram_bitslice) */
+    P.pk = pack(64);
+    P.slots = 64;
+    {
+        gkmpack::Packing wide = pack(gkmpack::MAX_ROWS);
+        if (getenv("GKM_FORCE_PACKED") ? !strcmp(getenv("GKM_FORCE_PACKED"), "128")
+                                       : (double)P.pk.ntiles > 1.04 * (double)wide.ntiles) {
+            P.pk = std::move(wide);
+            P.slots = gkmpack::MAX_ROWS;
+        }
+    }
+    const gkmpack::Packing &pk = P.pk;
+    const int W = pk.W, ntiles = pk.ntiles, slots = P.slots;
+    /* everything but a same-length problem whose rows fill whole lanes -- ragged one-piece data too -- takes the
+     * several-pieces variants */
+    bool packed = !unif || slots != 64;
+    for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
+    P.packed = packed;
+    P.kernel = gkm_pick_bitslice(!packed ? 4 : slots == 64 ? 1 : 2, L, d);
+    P.name = !packed ? "k_gram_bitslice<same length>" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+    if (!P.kernel) return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
+    const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
+    /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
+     * kernel depend on its occupancy? */
+    const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
+    /* dynamic LDS of a wave: the column's two packed strands + the column's weights by position with zeros either side
+     * (ctx->ptw words) + the centred distance table for the row side in the several-pieces variants (the same-length
+     * variant's rows read the column's table by position) */
+    P.dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad + (size_t)ctx->ptw * 4 + (packed ? (size_t)ctx->wdc_words * 4 : 0);
+    static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
+
+    const size_t nl = (size_t)ntiles * 64;
+    P.desc.assign(nl * gkmpack::MAX_PIECES * 5, 0);
+    P.lane_mask.assign(nl, 0u);
+    P.lane_piece.assign(nl * (size_t)LPW, 0u);
+    std::vector<int> fill(nl, 0);
+    for (const gkmpack::Piece &pc : pk.pieces) {
+        const int k = fill[(size_t)pc.lane]++;
+        int *dd = &P.desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
+        dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
+        P.lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
+        /* second profile copy (k_gram_bitslice two_copies): odd lanes of a tile with at most slots / 2 rows */
+        const bool second = 2 * pk.tile_nrows[(size_t)(pc.lane / 64)] <= slots && (pc.lane & 1);
+        const uint32_t slot = (uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u);
+        const int row_windows = ctx->h_len[(size_t)pc.row] - L + 1;
+        if (packed) {
+            /* slot | centre offset << 7 | owned windows << 20: the row l-mer at lane position i0 is i0 + 2048 - c0b l-mers
+             * away from its sequence's centre l-mer (signed; the bias keeps c0b unsigned) */
+            const uint32_t c0b = (uint32_t)(row_windows / 2 - pc.p0 + pc.b0 * W + 2048);
+            if (slot > 127 || c0b > 0x1FFFu || pc.cnt > 511) return set_err_msg("gram: piece entry out of range", 2);
+            P.lane_piece[(size_t)pc.lane * NP + k] = slot | (c0b << 7) | ((uint32_t)pc.cnt << 20);
+        } else {
+            /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index is the
+             * piece's first position over the lane capacity: pieces of a same-length problem fill whole lanes */
+            const int cap = gkmbs::segment_capacity(W, L) / own_mult * own_mult;
+            if (pc.b0 != 0 || pc.p0 % cap != 0 || pc.p0 / cap > 7 || slot > 63 || (pc.cnt % own_mult != 0 && pc.p0 + pc.cnt != row_windows))
+                return set_err_msg("gram: same-length packing broke its own rule", 2);
+            P.lane_piece[(size_t)pc.lane * 2] = (slot << gkmbs::META_SLOT_SHIFT) | ((uint32_t)(pc.p0 / cap) << gkmbs::META_PIECE_SHIFT);
+        }
+    }
+    P.cbeg.assign((size_t)ntiles, 0);
+    P.cend.assign((size_t)ntiles, 0);
+    P.soff.assign((size_t)ntiles + 1, 0);
+    for (int t = 0; t < ntiles; t++) {
+        int amin = n;
+        for (int rs = 0; rs < pk.tile_nrows[(size_t)t]; rs++) amin = std::min(amin, pk.tile_row[(size_t)t * gkmpack::MAX_ROWS + rs]);
+        P.cbeg[(size_t)t] = mode == COLS_DIAGONAL ? amin : 0;
+        P.cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
+        P.soff[(size_t)t + 1] = P.soff[(size_t)t] + (P.cend[(size_t)t] - P.cbeg[(size_t)t]);
+    }
+    if (P.soff[(size_t)ntiles] <= 0 || P.soff[(size_t)ntiles] > 0x7fffffffLL) return set_err_msg("gram: bad work item count", 2);
+    /* work-item order: (column chunk, tile) entries (BsArgs) where that is free.  Measured (tools/col_chunk_sweep2.sh,
+     * profiles/r4_col_chunk_sweep.txt; kernel ms / GB read from L2 misses per launch): config 2 plain order 72.4 / 5.48,
+     * chunks of 4 096 columns 72.5 / 0.19 -- the column tables (5.3 KB per 300-bp column) of a chunk, dealt over the 8
+     * XCDs, are 2.7 MB per L2 and stay there; config 5 151.2 / 12.1 against 151.8 / 2.3; gkmQC's shape (10.3 KB per
+     * column) 384.1 / 28.7 against 385.4 / 21.9 at 4 096 (5.3 MB per L2: no reuse) and 386.4 / 4.2 at 2 560.  SMALLER
+     * chunks cost time: the 28 waves of a CU then belong to 3-5 tiles instead of 1-2 and their hit paths evict each
+     * other's packed rows from the 32 KB L1 (1 024 columns: +2 % on config 2, +6 % on the other two).  The traffic
+     * binds nothing (80 GB/s against 8 TB/s), the kernel's time is what counts: chunks of 4 096 columns where a chunk's
+     * tables fit 3 MB per XCD (config 2, config 3), the plain tile-major order everywhere else.  GKM_COL_CHUNK=<columns>
+     * overrides, 0 = plain. */
+    P.n_items = P.soff[(size_t)ntiles];
+    const double mean_len = ctx->h_cum_n[(size_t)n] / n + (L - 1);
+    const double col_bytes = (4.0 * (mean_len + W) + 2.0 * (mean_len / 16.0 + 1.0)) * sizeof(uint32_t);
+    long chunk = col_bytes * 4096.0 / 8.0 <= 3.0 * 1048576.0 ? 4096 : 0;
+    if (const char *cc = getenv("GKM_COL_CHUNK")) chunk = atol(cc) & ~7L;
+    if (chunk >= 8 && chunk < n) {
+        int64_t at = 0;
+        for (long c0 = 0; c0 < n; c0 += chunk)
+            for (int t = 0; t < ntiles; t++) {
+                const int j0 = std::max<long>(P.cbeg[(size_t)t], c0), j1 = (int)std::min<long>(P.cend[(size_t)t], c0 + chunk);
+                if (j0 >= j1) continue;
+                P.ent_off.push_back(at);
+                P.ent_tile.push_back(t);
+                P.ent_j0.push_back(j0);
+                P.ent_j1.push_back(j1);
+                at += (j1 - j0 + 7) & ~7;
+            }
+        P.ent_off.push_back(at);
+        if (at > 0x7fffffffLL) { P.ent_off.clear(); P.ent_tile.clear(); P.ent_j0.clear(); P.ent_j1.clear(); } /* (too many items with the padding: plain order) */
+        else P.n_items = at;
+    }
+    return 0;
+}
+
+/* ---- the bit-sliced launch, device side: tables up in one copy, row planes, the Gram kernel, untile ---- */
+static int enqueue_bitslice(gkmhip_ctx *ctx, const BitslicePlan &P, int nrows, GramOut out, hipStream_t stream)
+{
+    const gkmpack::Packing &pk = P.pk;
+    const int W = pk.W, L = ctx->L, ntiles = pk.ntiles;
+    const size_t nl = (size_t)ntiles * 64;
+    /* every per-launch table goes to the device in ONE copy (the boundary call issues a few launches, a multi-GPU rank
+     * one per chunk) */
+    std::vector<char> blob;
+    auto put = [&](const void *src, size_t bytes) {
+        const size_t at = (blob.size() + 255) & ~(size_t)255;
+        blob.resize(at + bytes);
+        memcpy(blob.data() + at, src, bytes);
+        return at;
+    };
+    const size_t o_desc = put(P.desc.data(), P.desc.size() * sizeof(int));
+    const size_t o_mask = put(P.lane_mask.data(), nl * sizeof(uint32_t));
+    const size_t o_piece = put(P.lane_piece.data(), P.lane_piece.size() * sizeof(uint32_t));
+    const size_t o_trow = put(pk.tile_row.data(), pk.tile_row.size() * sizeof(int));
+    const size_t o_tout = put(pk.tile_out.data(), pk.tile_out.size() * sizeof(int));
+    const size_t o_tn = put(pk.tile_nrows.data(), (size_t)ntiles * sizeof(int));
+    const size_t o_cbeg = put(P.cbeg.data(), (size_t)ntiles * sizeof(int));
+    const size_t o_cend = put(P.cend.data(), (size_t)ntiles * sizeof(int));
+    const size_t o_soff = put(P.soff.data(), P.soff.size() * sizeof(int64_t));
+    const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
+    const int nent = (int)P.ent_tile.size();
+    const size_t o_eoff = nent ? put(P.ent_off.data(), P.ent_off.size() * sizeof(int64_t)) : 0;
+    const size_t o_etile = nent ? put(P.ent_tile.data(), (size_t)nent * sizeof(int)) : 0;
+    const size_t o_ej0 = nent ? put(P.ent_j0.data(), (size_t)nent * sizeof(int)) : 0;
+    const size_t o_ej1 = nent ? put(P.ent_j1.data(), (size_t)nent * sizeof(int)) : 0;
+    auto &scr = ctx->scratch[ctx->sel];
+    /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
+     * so that the lane field of a record's origin word is the lane's byte offset (gkm_bitslice.h pack_meta) */
+    const int rpw = 32;
+    static_assert(32 * 10 / 16 + 1 <= 32, "a lane's packed positions fit 128 bytes");
+    PinBuf *hb = pin_acquire(blob.size());
+    if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
+    if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) || scr.rowpk.ensure(nl * (size_t)rpw, true) ||
+        (out.G && scr.S.ensure((size_t)P.soff[(size_t)ntiles] * (size_t)P.slots, true))) {
+        pin_release(hb);
+        return 4;
+    }
+    /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
+     * may still be reading it after this function has returned and freed it */
+    memcpy(hb->p, blob.data(), blob.size());
+    {
+        hipError_t ce = hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream);
+        if (ce == hipSuccess && hipLaunchHostFunc(stream, pin_release, hb) != hipSuccess) {
+            ce = hipStreamSynchronize(stream); /* no host function: hand the buffer back once the copy is over */
+            pin_release(hb);
+        } else if (ce != hipSuccess) {
+            pin_release(hb);
+        }
+        HIPCHK(ce);
+    }
+    /* (This upload and the row-plane kernel are the ~0.1 ms between two Gram kernels of one stream.  A multi-GPU rank's
+     * transfer of the previous chunk needs exactly that head start to get onto the device: gkm_multi.hip rank_thread.) */
+    char *tb = scr.tables.p;
+    static_assert(10 * 4 >= 32, "plane 3: ten parts of four packed words cover the lane's 32");
+    hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4, (unsigned)W), dim3(64), 0, stream, ctx->codes.p, ctx->off.p,
+                       (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
+    HIPCHK(hipGetLastError());
+
+    BsArgs A;
+    A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
+    A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
+    A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
+    A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p;
+    A.rpw = rpw; A.pkw = ctx->pkw; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = P.same_length ? 0 : ctx->ptw;
+    A.cap = gkmbs::segment_capacity(W, L) / 5 * 5;
+    A.wdc = ctx->wdc.p; A.wdc_words = ctx->wdc_words; A.wdc_centre = ctx->wdc_centre;
+    A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
+    A.len = ctx->len.p;
+    for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+    A.out = out;
+    if (out.row_off) A.out.row_off = (const int64_t *)(tb + o_roff);
+    A.ntiles = ntiles;
+    A.S = out.G ? scr.S.p : nullptr;
+    A.tile_soff = (const int64_t *)(tb + o_soff);
+    A.nent = nent;
+    A.ent_off = (const int64_t *)(tb + o_eoff);
+    A.ent_tile = (const int *)(tb + o_etile);
+    A.ent_j0 = (const int *)(tb + o_ej0);
+    A.ent_j1 = (const int *)(tb + o_ej1);
+    /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what the drain at the end
+     * of every launch costs -- nothing for one big launch, 0.2-0.3 ms for each of a multi-GPU rank's chunks. */
+    hipEvent_t e0, e1;
+    if (gkm_launch_events(ctx, &e0, &e1)) return 4;
+    HIPCHK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(P.kernel, dim3((unsigned)P.n_items), dim3(64), P.dyn_lds, stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, stream));
+    if (out.G) {
+        int span = 0;
+        for (int t = 0; t < ntiles; t++) span = std::max(span, P.cend[(size_t)t] - P.cbeg[(size_t)t]);
+        const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (P.slots / UT_SLOTS)));
+        if (P.slots != 64)
+            hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
+                               A.tile_nrows, A.tile_row, A.tile_out, A.out);
+        else
+            hipLaunchKernelGGL(k_untile<64>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend, A.tile_nrows,
+                               A.tile_row, A.tile_out, A.out);
+        HIPCHK(hipGetLastError());
+    }
+    if (getenv("GKM_TRACE")) { /* the occupancy the runtime grants this instantiation with this much dynamic LDS */
+        int per_cu = 0;
+        hipFuncAttributes fa;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)P.kernel, 64, P.dyn_lds) == hipSuccess &&
+            hipFuncGetAttributes(&fa, (const void *)P.kernel) == hipSuccess)
+            fprintf(stderr, "gkmhip: hot kernel: %d VGPRs, %zu + %zu bytes of LDS per wave, %d one-wave workgroups per CU\n",
+                    fa.numRegs, (size_t)fa.sharedSizeBytes, P.dyn_lds, per_cu);
+    }
+    ctx->last_kernel = P.name;
+    return 0;
+}
+
+/* ---- the general kernel's launch ---- */
+static int enqueue_direct(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, GramOut out, hipStream_t stream)
+{
+    const int n = ctx->n;
+    auto &scr = ctx->scratch[ctx->sel];
+    if (ensure_lmers(ctx, stream)) return 4;
+    if (scr.rows.ensure((size_t)nrows)) return 4;
+    HIPCHK(hipMemcpyAsync(scr.rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
+    if (out.row_off) {
+        if (scr.rowoff.ensure((size_t)nrows)) return 4;
+        HIPCHK(hipMemcpyAsync(scr.rowoff.p, out.row_off, (size_t)nrows * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        out.row_off = scr.rowoff.p;
+    }
+    HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
+    DirectArgs A;
+    A.rows = scr.rows.p; A.nrows = nrows;
+    A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
+    for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
+    A.out = out;
+    A.L = ctx->L; A.d = ctx->d; A.mode = mode; A.n = n;
+    const unsigned ntiles = (unsigned)((nrows + 63) / 64);
+    int span = 0; /* widest column range of any 64-row tile */
+    double items = 0; /* (tile, column) pairs of the launch */
+    for (unsigned t = 0; t < ntiles; t++) {
+        const int amin = rows[t * 64], amax = rows[std::min<int>((int)t * 64 + 63, nrows - 1)];
+        const int cols = mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1;
+        span = std::max(span, cols);
+        items += cols;
+    }
+    /* columns per workgroup: 16 where that still gives the GPU ~16 waves per SIMD, fewer for small problems (2 000
+     * sequences: 2 000 workgroups of 16 columns left three quarters of the SIMDs idle, 156 ms; now 2 columns) */
+    A.cj = (int)std::min(16.0, std::max(1.0, floor(items / 16384.0)));
+    const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
+    hipEvent_t e0, e1;
+    if (gkm_launch_events(ctx, &e0, &e1)) return 4;
+    HIPCHK(hipEventRecord(e0, stream));
+    hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(e1, stream));
+    ctx->last_kernel = "k_gram_direct";
+    return 0;
+}
+
+/* One launch of the Gram kernel for a set of rows (mode: see plan_bitslice). */
 static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, GramOut out, hipStream_t stream)
 {
     if (!ctx || !rows || nrows <= 0) return set_err_msg("gram: bad arguments", 2);
@@ -242,290 +544,21 @@ static int gram_launch(gkmhip_ctx *ctx, const int *rows, int nrows, int mode, Gr
         comparisons += 2.0 * na * (mode == COLS_FULL ? ctx->h_cum_n[(size_t)n] : mode == COLS_DIAGONAL ? na : ctx->h_cum_n[(size_t)rows[i] + 1]);
     }
     out.write_all = mode == COLS_FULL ? 1 : 0;
-
-    /* W = 10 words per lane; W = 20 was measured too (config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms):
-     * the longer per-shift chain does not pay for the registers it costs */
-    bs_kernel_t bs10 = nullptr;
-    if (ctx->kernel_pref != GKMHIP_KERNEL_DIRECT) bs10 = gkm_pick_bitslice(2, L, d);
-    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !bs10)
+    /* (W = 10 words per lane; W = 20 was measured too -- config 2: 121 vs 118 ms, 150 bp: 56 vs 31 ms in round 1: the longer
+     * per-shift chain does not pay for the registers it costs) */
+    if (ctx->kernel_pref == GKMHIP_KERNEL_BITSLICE && !gkm_pick_bitslice(2, L, d))
         return set_err_msg("bit-sliced kernel not instantiated for this (L, d)", 5);
-    if (!bitslice_serves(ctx)) bs10 = nullptr; /* auto: the general kernel where it is the faster one */
-
-    if (bs10) {
-        /* pack the rows into lanes at bit-row granularity (gkm_pack.h) */
-        std::vector<int> nwin((size_t)nrows);
-        for (int i = 0; i < nrows; i++) nwin[(size_t)i] = ctx->h_len[(size_t)rows[i]] - L + 1;
-        /* At most 64 rows per tile unless that leaves lanes empty (rows shorter than half a lane): the
-         * 64-slot kernels keep a wave more per SIMD (k_gram_bitslice) */
-        /* (a jump in the row list -- a multi-GPU rank's two folded row blocks -- closes the tile where that means fewer
-         * work items: gkm_pack.h) */
-        /* Every variant resolves hits by GROUPS of five lane positions (k_gram_bitslice): a piece that does not finish
-         * its row owns a multiple of five windows.  Same-length problems take the variant that needs neither piece table nor
-         * permute (PK = 4); GKM_FORCE_PACKED=1|128 (tests, A/B runs) puts them on the several-pieces variants. */
-        const bool same_length = ctx->minlen == ctx->maxlen;
-        const bool unif = same_length && getenv("GKM_FORCE_PACKED") == nullptr && gkm_pick_bitslice(4, L, d) != nullptr;
-        const int own_mult = 5;
-        auto pack = [&](int max_rows) {
-            gkmpack::Packing a = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, 0, own_mult);
-            if (mode == COLS_FULL || rows[nrows - 1] - rows[0] + 1 == nrows) return a; /* (no jump, or every tile visits all columns) */
-            gkmpack::Packing b = gkmpack::pack_rows(rows, nwin.data(), nrows, 10, L, max_rows, gkmpack::LANES, own_mult);
-            return gkmpack::triangle_items(b) < gkmpack::triangle_items(a) ? b : a;
-        };
-        gkmpack::Packing pk = pack(64);
-        int slots = 64;
-        {
-            gkmpack::Packing wide = pack(gkmpack::MAX_ROWS);
-            if (getenv("GKM_FORCE_PACKED") ? !strcmp(getenv("GKM_FORCE_PACKED"), "128")
-                                           : (double)pk.ntiles > 1.04 * (double)wide.ntiles) {
-                pk = std::move(wide);
-                slots = gkmpack::MAX_ROWS;
-            }
-        }
-        const int W = pk.W, ntiles = pk.ntiles;
-        /* everything but a same-length problem whose rows fill whole lanes -- ragged one-piece data too -- takes the
-         * several-pieces variants */
-        bool packed = !unif || slots != 64;
-        for (size_t k = 1; k < pk.pieces.size() && !packed; k++) packed = pk.pieces[k].lane == pk.pieces[k - 1].lane;
-        const int NP = packed ? gkmpack::MAX_PIECES : 1, LPW = packed ? NP : 2;
-        bs_kernel_t bs = !packed ? gkm_pick_bitslice(4, L, d) : slots == 64 ? gkm_pick_bitslice(1, L, d) : bs10;
-        /* (normally built by gkmhip_set_sequences; before ctx->pkw sizes the dynamic LDS below) */
-        if (ensure_sb(ctx, W, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream)) return 4;
-        /* GKM_LDS_PAD=<bytes> (experiments): extra dynamic LDS per wave, i.e. fewer waves per CU -- how much does the
-         * kernel depend on its occupancy? */
-        const size_t lds_pad = getenv("GKM_LDS_PAD") ? (size_t)atoi(getenv("GKM_LDS_PAD")) : 0;
-        /* dynamic LDS of a wave: the column's two packed strands + the column's weights by position with zeros either side
-         * (ctx->ptw words) + the centred distance table for the row side in the several-pieces variants (the same-length
-         * variant's rows read the column's table by position) */
-        const size_t postab_bytes = (size_t)ctx->ptw * 4;
-        const size_t dyn_lds = (size_t)(2 * ctx->pkw) * sizeof(uint32_t) + lds_pad + postab_bytes + (packed ? (size_t)ctx->wdc_words * 4 : 0);
-        static_assert(GKM_MAXLEN / (32 * 10 - 11) <= 7, "a row's piece index fits the 3 bits of the origin word");
-        auto nwin_of = [&](int row) { return ctx->h_len[(size_t)row] - L + 1; };
-        const size_t nl = (size_t)ntiles * 64;
-        std::vector<int> desc(nl * gkmpack::MAX_PIECES * 5, 0);
-        std::vector<uint32_t> lane_mask(nl, 0u), lane_piece(nl * (size_t)LPW, 0u);
-        std::vector<int> fill(nl, 0);
-        for (const gkmpack::Piece &pc : pk.pieces) {
-            const int k = fill[(size_t)pc.lane]++;
-            int *dd = &desc[((size_t)pc.lane * gkmpack::MAX_PIECES + k) * 5];
-            dd[0] = pc.row; dd[1] = pc.b0; dd[2] = pc.nb; dd[3] = pc.p0; dd[4] = pc.cnt;
-            lane_mask[(size_t)pc.lane] |= 1u << pc.b0;
-            /* byte offset of the row slot in accl[m][.]; the row l-mer at lane position i0 is |c0 - i0| l-mers
-             * away from its sequence's centre l-mer, c0 > -2048 is stored with a bias of 2048 so that the
-             * kernel's unsigned |a - b| applies */
-            /* second profile copy (k_gram_bitslice two_copies): odd lanes of a tile with at most slots / 2 rows */
-            const int tile_of = pc.lane / 64;
-            const bool second = 2 * pk.tile_nrows[(size_t)tile_of] <= slots && (pc.lane & 1);
-            const uint32_t slot4 = ((uint32_t)pc.slot + (second ? (uint32_t)slots / 2u : 0u)) * 4u;
-            const uint32_t c0b = (uint32_t)((ctx->h_len[(size_t)pc.row] - L + 1) / 2 - pc.p0 + pc.b0 * W + 2048);
-            if (packed) { /* slot | centre offset << 7 | owned windows << 20 (k_gram_bitslice) */
-                if (slot4 / 4 > 127 || c0b > 0x1FFFu || pc.cnt > 511) return set_err_msg("gram: piece entry out of range", 2);
-                lane_piece[(size_t)pc.lane * NP + k] = (slot4 / 4u) | (c0b << 7) | ((uint32_t)pc.cnt << 20);
-            } else {
-                /* row slot and piece index where the record's origin word wants them (gkm_bitslice.h); the piece index
-                 * is the piece's first position over the lane capacity: pieces of a same-length problem fill whole lanes */
-                const int cap = gkmbs::segment_capacity(W, L) / 5 * 5; /* (own_mult = 5) */
-                if (pc.b0 != 0 || pc.p0 % cap != 0 || pc.p0 / cap > 7 || slot4 / 4 > 63 || (pc.cnt % 5 != 0 && pc.p0 + pc.cnt != nwin_of(pc.row)))
-                    return set_err_msg("gram: same-length packing broke its own rule", 2);
-                lane_piece[(size_t)pc.lane * 2] = ((slot4 / 4u) << gkmbs::META_SLOT_SHIFT) |
-                                                  ((uint32_t)(pc.p0 / cap) << gkmbs::META_PIECE_SHIFT);
-            }
-        }
-        /* columns [cbeg, cend) per tile */
-        std::vector<int> cbeg((size_t)ntiles, 0), cend((size_t)ntiles, 0);
-        std::vector<int64_t> soff((size_t)ntiles + 1, 0);
-        for (int t = 0; t < ntiles; t++) {
-            int amin = n;
-            for (int rs = 0; rs < pk.tile_nrows[(size_t)t]; rs++) amin = std::min(amin, pk.tile_row[(size_t)t * gkmpack::MAX_ROWS + rs]);
-            cbeg[(size_t)t] = mode == COLS_DIAGONAL ? amin : 0;
-            cend[(size_t)t] = mode == COLS_FULL ? n : pk.tile_amax[(size_t)t] + 1;
-            soff[(size_t)t + 1] = soff[(size_t)t] + (cend[(size_t)t] - cbeg[(size_t)t]);
-        }
-        if (soff[(size_t)ntiles] <= 0 || soff[(size_t)ntiles] > 0x7fffffffLL) return set_err_msg("gram: bad work item count", 2);
-
-        /* every per-launch table goes to the device in ONE copy (the boundary call issues 13 launches) */
-        std::vector<char> blob;
-        auto put = [&](const void *src, size_t bytes) {
-            const size_t at = (blob.size() + 255) & ~(size_t)255;
-            blob.resize(at + bytes);
-            memcpy(blob.data() + at, src, bytes);
-            return at;
-        };
-        const size_t o_desc = put(desc.data(), desc.size() * sizeof(int));
-        const size_t o_mask = put(lane_mask.data(), nl * sizeof(uint32_t));
-        const size_t o_piece = put(lane_piece.data(), lane_piece.size() * sizeof(uint32_t));
-        const size_t o_trow = put(pk.tile_row.data(), pk.tile_row.size() * sizeof(int));
-        const size_t o_tout = put(pk.tile_out.data(), pk.tile_out.size() * sizeof(int));
-        const size_t o_tn = put(pk.tile_nrows.data(), (size_t)ntiles * sizeof(int));
-        const size_t o_cbeg = put(cbeg.data(), (size_t)ntiles * sizeof(int));
-        const size_t o_cend = put(cend.data(), (size_t)ntiles * sizeof(int));
-        const size_t o_soff = put(soff.data(), soff.size() * sizeof(int64_t));
-        const size_t o_roff = out.row_off ? put(out.row_off, (size_t)nrows * sizeof(int64_t)) : 0;
-        /* work-item order: (column chunk, tile) entries (BsArgs) where that is free.  Measured (tools/col_chunk_sweep2.sh,
-         * profiles/r4_col_chunk_sweep.txt; kernel ms / GB read from L2 misses per launch): config 2 plain order 72.4 / 5.48,
-         * chunks of 4 096 columns 72.5 / 0.19 -- the column tables (5.3 KB per 300-bp column) of a chunk, dealt over the 8
-         * XCDs, are 2.7 MB per L2 and stay there; config 5 151.2 / 12.1 against 151.8 / 2.3; gkmQC's shape (10.3 KB per
-         * column) 384.1 / 28.7 against 385.4 / 21.9 at 4 096 (5.3 MB per L2: no reuse) and 386.4 / 4.2 at 2 560.  SMALLER
-         * chunks cost time: the 28 waves of a CU then belong to 3-5 tiles instead of 1-2 and their hit paths evict each
-         * other's packed rows from the 32 KB L1 (1 024 columns: +2 % on config 2, +6 % on the other two).  The traffic
-         * binds nothing (80 GB/s against 8 TB/s), the kernel's time is what counts: chunks of 4 096 columns where a chunk's
-         * tables fit 3 MB per XCD (config 2, config 3), the plain tile-major order everywhere else.  GKM_COL_CHUNK=<columns>
-         * overrides, 0 = plain. */
-        std::vector<int64_t> ent_off;
-        std::vector<int> ent_tile, ent_j0, ent_j1;
-        int64_t n_items = soff[(size_t)ntiles];
-        {
-            const double mean_len = ctx->h_cum_n[(size_t)n] / n + (L - 1);
-            const double col_bytes = (4.0 * (mean_len + W) + 2.0 * (mean_len / 16.0 + 1.0)) * sizeof(uint32_t);
-            long chunk = col_bytes * 4096.0 / 8.0 <= 3.0 * 1048576.0 ? 4096 : 0;
-            if (const char *cc = getenv("GKM_COL_CHUNK")) chunk = atol(cc) & ~7L;
-            if (chunk >= 8 && chunk < n) {
-                int64_t at = 0;
-                for (long c0 = 0; c0 < n; c0 += chunk)
-                    for (int t = 0; t < ntiles; t++) {
-                        const int j0 = std::max<long>(cbeg[(size_t)t], c0), j1 = (int)std::min<long>(cend[(size_t)t], c0 + chunk);
-                        if (j0 >= j1) continue;
-                        ent_off.push_back(at);
-                        ent_tile.push_back(t);
-                        ent_j0.push_back(j0);
-                        ent_j1.push_back(j1);
-                        at += (j1 - j0 + 7) & ~7;
-                    }
-                ent_off.push_back(at);
-                if (at > 0x7fffffffLL) { ent_off.clear(); ent_tile.clear(); } /* (too many items with the padding: plain order) */
-                else n_items = at;
-            }
-        }
-        const int nent = (int)ent_tile.size();
-        const size_t o_eoff = nent ? put(ent_off.data(), ent_off.size() * sizeof(int64_t)) : 0;
-        const size_t o_etile = nent ? put(ent_tile.data(), (size_t)nent * sizeof(int)) : 0;
-        const size_t o_ej0 = nent ? put(ent_j0.data(), (size_t)nent * sizeof(int)) : 0;
-        const size_t o_ej1 = nent ? put(ent_j1.data(), (size_t)nent * sizeof(int)) : 0;
-        const int NS = slots;
-        auto &scr = ctx->scratch[ctx->sel];
-        /* (The tables and row planes on a second stream and untile on a third, so that the Gram kernels of the drop-in
-         * call's row blocks follow each other with nothing in between, was built and measured in round 4: k_untile's
-         * 33 KB workgroups then wait for room beside the next block's Gram kernel -- its 28 waves per CU leave 17 KB of
-         * LDS -- and finish only when it does; the copies start one block late: 90.6 instead of 81.4 ms for the call.) */
-        /* words of a lane's packed positions: 32 W / 16 + 1 are used (the hit path reads two); the stride is 128 bytes,
-         * so that the lane field of a record's origin word is the lane's byte offset (gkm_bitslice.h pack_meta) */
-        const int rpw = 32;
-        static_assert(32 * 10 / 16 + 1 <= 32, "a lane's packed positions fit 128 bytes");
-        PinBuf *hb = pin_acquire(blob.size());
-        if (!hb) return set_err_msg("gram: pinned host buffer for the launch tables", 4);
-        if (scr.tables.ensure(blob.size(), true) || scr.rowplanes.ensure(nl * 3 * W, true) ||
-            scr.rowpk.ensure(nl * (size_t)rpw, true) ||
-            (out.G && scr.S.ensure((size_t)soff[(size_t)ntiles] * (size_t)NS, true))) {
-            pin_release(hb);
-            return 4;
-        }
-        /* through a pinned buffer that outlives the call: an asynchronous copy from a local (pageable) vector
-         * may still be reading it after this function has returned and freed it */
-        memcpy(hb->p, blob.data(), blob.size());
-        {
-            hipError_t ce = hipMemcpyAsync(scr.tables.p, hb->p, blob.size(), hipMemcpyHostToDevice, stream);
-            if (ce == hipSuccess && hipLaunchHostFunc(stream, pin_release, hb) != hipSuccess) {
-                ce = hipStreamSynchronize(stream); /* no host function: hand the buffer back once the copy is over */
-                pin_release(hb);
-            } else if (ce != hipSuccess) {
-                pin_release(hb);
-            }
-            HIPCHK(ce);
-        }
-        char *tb = scr.tables.p;
-        static_assert(10 * 4 >= 32, "plane 3: ten parts of four packed words cover the lane's 32");
-        hipLaunchKernelGGL(k_build_rowplanes, dim3((unsigned)ntiles, 4, (unsigned)W), dim3(64), 0, stream, ctx->codes.p,
-                           ctx->off.p, (const int *)(tb + o_desc), W, scr.rowplanes.p, scr.rowpk.p, rpw);
-        HIPCHK(hipGetLastError());
-
-        BsArgs A;
-        A.rowplanes = scr.rowplanes.p; A.lane_mask = (const uint32_t *)(tb + o_mask); A.lane_piece = (const uint32_t *)(tb + o_piece);
-        A.tile_row = (const int *)(tb + o_trow); A.tile_out = (const int *)(tb + o_tout); A.tile_nrows = (const int *)(tb + o_tn);
-        A.tile_cbeg = (const int *)(tb + o_cbeg); A.tile_cend = (const int *)(tb + o_cend);
-        A.rowpk = scr.rowpk.p; A.colpk = ctx->colpk.p;
-        A.rpw = rpw; A.pkw = ctx->pkw; A.postab = ctx->postab.p; A.ptw = ctx->ptw; A.ptw_stride = same_length ? 0 : ctx->ptw;
-        A.cap = gkmbs::segment_capacity(W, L) / 5 * 5;
-        A.wdc = ctx->wdc.p; A.wdc_words = ctx->wdc_words; A.wdc_centre = ctx->wdc_centre;
-        A.sb = ctx->sb.p; A.xw = ctx->sb_xw;
-        A.len = ctx->len.p;
-        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
-        A.out = out;
-        if (out.row_off) A.out.row_off = (const int64_t *)(tb + o_roff);
-        A.ntiles = ntiles;
-        A.S = out.G ? scr.S.p : nullptr;
-        A.tile_soff = (const int64_t *)(tb + o_soff);
-        A.nent = nent;
-        A.ent_off = (const int64_t *)(tb + o_eoff);
-        A.ent_tile = (const int *)(tb + o_etile);
-        A.ent_j0 = (const int *)(tb + o_ej0);
-        A.ent_j1 = (const int *)(tb + o_ej1);
-        /* One column sequence per work item: a wave of the full-size problem lives ~0.6 ms, which is what
-         * the drain at the end of every launch costs -- nothing for one big launch, but the boundary call
-         * issues 13 launches and the multi-GPU path one per chunk. */
-        hipEvent_t e0, e1;
-        if (gkm_launch_events(ctx, &e0, &e1)) return 4;
-        HIPCHK(hipEventRecord(e0, stream));
-        hipLaunchKernelGGL(bs, dim3((unsigned)n_items), dim3(64), dyn_lds, stream, A);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e1, stream));
-        if (out.G) {
-            int span = 0;
-            for (int t = 0; t < ntiles; t++) span = std::max(span, cend[(size_t)t] - cbeg[(size_t)t]);
-            const dim3 ug((unsigned)((span + 63) / 64), (unsigned)(ntiles * (NS / UT_SLOTS)));
-            if (slots != 64)
-                hipLaunchKernelGGL(k_untile<gkmpack::MAX_ROWS>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg,
-                                   A.tile_cend, A.tile_nrows, A.tile_row, A.tile_out, A.out);
-            else
-                hipLaunchKernelGGL(k_untile<64>, ug, dim3(64), 0, stream, scr.S.p, A.tile_soff, A.tile_cbeg, A.tile_cend,
-                                   A.tile_nrows, A.tile_row, A.tile_out, A.out);
-            HIPCHK(hipGetLastError());
-        }
-        if (getenv("GKM_TRACE")) { /* the occupancy the runtime grants this instantiation with this much dynamic LDS */
-            int per_cu = 0;
-            hipFuncAttributes fa;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)bs, 64, dyn_lds) == hipSuccess &&
-                hipFuncGetAttributes(&fa, (const void *)bs) == hipSuccess)
-                fprintf(stderr, "gkmhip: hot kernel: %d VGPRs, %zu + %zu bytes of LDS per wave, %d one-wave workgroups per CU\n",
-                        fa.numRegs, (size_t)fa.sharedSizeBytes, dyn_lds, per_cu);
-        }
-        ctx->last_kernel = !packed ? "k_gram_bitslice<same length>" : slots == 64 ? "k_gram_bitslice<packed>" : "k_gram_bitslice<packed,128>";
+    int rc;
+    if (bitslice_serves(ctx)) { /* (auto: the general kernel where it is the faster one) */
+        /* the per-sequence tables (normally built by gkmhip_set_sequences); ctx->pkw and ctx->ptw size the plan's dynamic LDS */
+        if (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream)) return 4;
+        BitslicePlan P;
+        rc = plan_bitslice(ctx, rows, nrows, mode, P);
+        if (!rc) rc = enqueue_bitslice(ctx, P, nrows, out, stream);
     } else {
-        if (ensure_lmers(ctx, stream)) return 4;
-        if (ctx->scratch[ctx->sel].rows.ensure((size_t)nrows)) return 4;
-        HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rows.p, rows, (size_t)nrows * sizeof(int), hipMemcpyHostToDevice, stream));
-        if (out.row_off) {
-            if (ctx->scratch[ctx->sel].rowoff.ensure((size_t)nrows)) return 4;
-            HIPCHK(hipMemcpyAsync(ctx->scratch[ctx->sel].rowoff.p, out.row_off, (size_t)nrows * sizeof(int64_t),
-                                  hipMemcpyHostToDevice, stream));
-            out.row_off = ctx->scratch[ctx->sel].rowoff.p;
-        }
-        HIPCHK(hipStreamSynchronize(stream)); /* `rows` is the caller's: see gkmhip_set_sequences */
-        DirectArgs A;
-        A.rows = ctx->scratch[ctx->sel].rows.p; A.nrows = nrows;
-        A.len = ctx->len.p; A.lmoff = ctx->lmoff.p; A.lmf = ctx->lmf.p; A.lmr = ctx->lmf.p + ctx->lm_stride;
-        for (int m = 0; m < GKM_MAXD1; m++) A.c[m] = ctx->c[m];
-        A.out = out;
-        A.L = L; A.d = d; A.mode = mode; A.n = n;
-        const unsigned ntiles = (unsigned)((nrows + 63) / 64);
-        int span = 0; /* widest column range of any 64-row tile */
-        double items = 0; /* (tile, column) pairs of the launch */
-        for (unsigned t = 0; t < ntiles; t++) {
-            const int amin = rows[t * 64], amax = rows[std::min<int>((int)t * 64 + 63, nrows - 1)];
-            const int cols = mode == COLS_FULL ? n : mode == COLS_DIAGONAL ? amax + 1 - amin : amax + 1;
-            span = std::max(span, cols);
-            items += cols;
-        }
-        /* columns per workgroup: 16 where that still gives the GPU ~16 waves per SIMD, fewer for small problems (2 000
-         * sequences: 2 000 workgroups of 16 columns left three quarters of the SIMDs idle, 156 ms; now 2 columns) */
-        A.cj = (int)std::min(16.0, std::max(1.0, floor(items / 16384.0)));
-        const unsigned nchunks = (unsigned)((span + A.cj - 1) / A.cj);
-        hipEvent_t e0, e1;
-        if (gkm_launch_events(ctx, &e0, &e1)) return 4;
-        HIPCHK(hipEventRecord(e0, stream));
-        hipLaunchKernelGGL(k_gram_direct, dim3(nchunks, ntiles), dim3(64), 0, stream, A);
-        HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(e1, stream));
-        ctx->last_kernel = "k_gram_direct";
+        rc = enqueue_direct(ctx, rows, nrows, mode, out, stream);
     }
+    if (rc) return rc;
     ctx->ev_valid = true;
     ctx->last_comparisons = comparisons;
     if (getenv("GKM_TRACE")) /* which kernel served this launch, and the rule's input: a regression on data far from iid shows here */
