@@ -375,10 +375,11 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
         ctx->wdc_words = bytes / 4;
         ctx->wdc_centre = centre;
     }
-    /* The per-sequence device tables are built HERE, not at the first launch: callers alternate launches between
-     * two streams (gkm_multi.hip, bench.py), and a table built by the first launch on one stream was read by the
-     * second launch on the other stream before it was complete (found when the host stopped waiting for its
-     * uploads: the config-4 stand-in through two contexts differed in a few hundred rows). */
+    /* The per-sequence device tables are built HERE, not at the first launch: callers may alternate launches between
+     * two streams (the scratch slots of gkmhip_set_scratch_slot; gkm_multi.hip and bench.py did until round 5), and a
+     * table built by the first launch on one stream was read by the second launch on the other stream before it was
+     * complete (found when the host stopped waiting for its uploads: the config-4 stand-in through two contexts differed
+     * in a few hundred rows). */
     if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream))) return 4;
     if (!bitslice_serves(ctx) && ensure_lmers(ctx, stream)) return 4;
     /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be

@@ -61,7 +61,7 @@ __global__ void k_build_rowplanes(const uint8_t *__restrict__ codes, const int64
  * such a workgroup cannot START beside a Gram kernel -- whose 28 one-wave workgroups per CU leave 17-20 KB of LDS and no
  * four free wave slots at one time -- so the untile of a multi-GPU rank's chunk c, on its own stream, ended when the Gram
  * kernel of chunk c+1 did and the transfer of chunk c hid behind nothing (round 5, tools/rank_alone.py,
- * profiles/r5_rank_alone_streams.txt).  grid (column blocks, tiles * NSLOT / UT_SLOTS). */
+ * profiles/r5_rank_alone_stream_policies.txt).  grid (column blocks, tiles * NSLOT / UT_SLOTS). */
 constexpr int UT_SLOTS = 16;
 template <int NSLOT>
 __global__ __launch_bounds__(64) void k_untile(const double *__restrict__ S, const int64_t *__restrict__ tile_soff,

@@ -150,7 +150,7 @@ private:
 
 /* Everything a rank needs besides its context, kept from call to call (bin/gkmqc.py asks for ~20 matrices of the
  * same size per run): the slab of this rank's rows, the gathered slabs of all ranks, the gather index, the self
- * norms, three streams and the events.  hipMalloc / hipFree synchronise the whole device, so a call that allocated
+ * norms, the compute and the transfer stream and the events.  hipMalloc / hipFree synchronise the whole device, so a call that allocated
  * ~1.7 GB and freed it again paid for that beside a ~10 ms kernel on 8 GPUs.  Keyed by (device, n, ranks, chunks);
  * rebuilt when any of them changes, freed by gkmhip_release_comms(). */
 struct RankCache {
@@ -189,7 +189,7 @@ void cache_release(RankCache &R)
 
 /* How many compute streams a rank's chunk launches alternate between: ONE.  Rounds 2-5 used two ("the kernel of chunk c+1
  * overlaps the drain of chunk c"), and round 5 measured what that does (tools/rank_alone.py prints when each chunk ran,
- * profiles/r5_rank_alone_streams.txt): two launches on two streams run CONCURRENTLY, workgroup by workgroup, and complete
+ * profiles/r5_rank_alone_c2_two_streams.txt, r5_rank_alone_stream_policies.txt): two launches on two streams run CONCURRENTLY, workgroup by workgroup, and complete
  * together -- chunk 0 of 2 ended at 8.63 ms of a rank's 8.88 -- so nothing of chunk 0's transfer hid behind chunk 1's
  * kernel, which is the only reason to cut a rank's rows into chunks.  (Stream priorities do not repair it: the
  * higher-priority launch gets ~60 % of the device, and its small kernels that follow ended with the OTHER launch in
