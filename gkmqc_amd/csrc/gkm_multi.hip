@@ -458,7 +458,7 @@ extern "C" int gkmhip_gram_rank_alone(gkmhip_ctx *ctx, int rank, int ranks, int 
     C.G = ranks;
     C.n = gkmhip_n_sequences(ctx);
     if (C.n <= 0 || ld < C.n) return fail_with("gkmhip_gram_rank_alone: no sequences uploaded or leading dimension too small", 2);
-    C.chunks = ranks == 1 ? 1 : (chunks > 0 ? chunks : gkmshard::auto_chunks(C.n, ranks));
+    C.chunks = chunks > 0 ? chunks : (ranks == 1 ? 1 : gkmshard::auto_chunks(C.n, ranks));
     C.pe = gkmshard::packed_chunk_elems(C.n, ranks, C.chunks);
     const RankCache &R = g_cache[rank];
     C.nsk = compute_streams();
@@ -514,7 +514,9 @@ extern "C" int gkmhip_gram_allgather(gkmhip_ctx **ctxs, int nctx, double **K, in
         for (int h = 0; h < g; h++) distinct = distinct && C.devs[(size_t)h] != C.devs[(size_t)g];
     }
     if (C.n <= 0 || ld < C.n) { return fail_with("gkmhip_gram_allgather: no sequences uploaded or leading dimension too small", 2); }
-    C.chunks = nctx == 1 ? 1 : (chunks > 0 ? chunks : gkmshard::auto_chunks(C.n, nctx));
+    /* (one context: one chunk unless the caller asks -- the tests do, to run the chunked sequence of launches, events and
+     * collectives through a one-rank RCCL communicator on a box with one GPU) */
+    C.chunks = chunks > 0 ? chunks : (nctx == 1 ? 1 : gkmshard::auto_chunks(C.n, nctx));
     C.pe = gkmshard::packed_chunk_elems(C.n, nctx, C.chunks);
     C.row_offset = gkmshard::packed_gather_offsets(C.n, nctx, C.chunks);
     g_bytes_per_rank = (long long)C.chunks * (nctx - 1) * (long long)C.pe * 8;

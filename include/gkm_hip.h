@@ -148,7 +148,7 @@ int gkmhip_gram_part_to_host_rows(gkmhip_ctx *ctx, double *G, int64_t ld, double
  * K[g]: device pointer ON ctxs[g]'s DEVICE to an n x ld matrix that receives K (lower triangle +
  * unit diagonal, the upper triangle too if symmetric != 0) -- the same matrix, bit for bit, as
  * gkmhip_gram_rows + gkmhip_normalize produce on one device.  chunks: slabs per rank whose transfer
- * overlaps the next slab's kernel (0 = chosen from (n, nctx): 2, or 3 / 4 where that pads the slabs 3 % less -- gkm_shard.h auto_chunks).  One host thread per device for the duration of
+ * overlaps the next slab's kernel (0 = chosen from (n, nctx): 1 for one context, else 2, or 3 / 4 where that pads the slabs 3 % less -- gkm_shard.h auto_chunks).  One host thread per device for the duration of
  * the call; blocks until every device holds the matrix.  This is what feeds the GPU-resident
  * cross-validation (include/gkm_svm.h) from an N-GPU matrix; the reference's consumer is
  * scripts/gkmsvm.py:104-122. */

@@ -765,6 +765,13 @@ def test_one_process_assembly_through_rccl(dev, monkeypatch):
         res = dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0])
         assert res["transport"] == "rccl"
         assert torch.equal(res["K"][0], one)
+    # the CHUNKED sequence (chunk c's all-gather on the transfer stream beside the kernel of chunk c + 1 on the compute
+    # stream, the host-side agreement before and after every collective) through the same one-rank communicator
+    for chunks in (2, 3):
+        res = dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0], chunks=chunks)
+        assert res["transport"] == "rccl" and torch.equal(res["K"][0], one)
+        st = dev.allgather_stats()
+        assert st["chunks"] == chunks and st["transport"] == "rccl" and st["transfer_ms"][0] > 0
     with pytest.raises(dev.GkmError):   # RCCL refuses one device twice; the call must fail cleanly, not hang
         dev.gram_matrix_multi(problem, 4, 11, 7, 3, devices=[0, 0])
     dev.load().gkmhip_release_comms()
