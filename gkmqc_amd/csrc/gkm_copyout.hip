@@ -79,6 +79,18 @@ extern "C" int gkmhip_probe_copy(void *dst, const void *src, size_t bytes, int b
     return 0;
 }
 
+/* Measurement only: `blocks` workgroups of `threads` threads that do nothing but watch the clock for `microseconds` -- a
+ * stand-in for a collective's workgroups waiting for their peers while they hold their wave slots. */
+extern "C" int gkmhip_probe_spin(int blocks, int threads, int microseconds, void *stream)
+{
+    if (blocks < 1 || threads < 64 || threads > 1024 || microseconds < 1 || microseconds > 100000)
+        return set_err_msg("gkmhip_probe_spin: bad arguments", 2);
+    hipLaunchKernelGGL(k_spin, dim3((unsigned)blocks), dim3((unsigned)threads), 0, (hipStream_t)stream, (long long)microseconds * 100,
+                       (unsigned *)nullptr);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 /* what the drop-in call's copy-out pipeline measured last time (gram_part_to_host_rows cuts its row blocks by it) */
 static struct {
     std::mutex m;

@@ -210,6 +210,9 @@ void *gkmhip_create_stream_beside_prio(void *const *busy, int nbusy, int *beside
 void *gkmhip_create_stream_reserving(void *const *busy, int nbusy, int *beside, int reserve_cus);
 /* Keeps `stream` busy for `microseconds` (at most 10 000) with one wave that does nothing. */
 int gkmhip_pause_stream(void *stream, int microseconds);
+/* Measurement only: `blocks` workgroups of `threads` threads that hold their wave slots for `microseconds` and do nothing
+ * (a collective's workgroups waiting for their peers). */
+int gkmhip_probe_spin(int blocks, int threads, int microseconds, void *stream);
 /* Measurement only: copies `bytes` (a multiple of 16) on the device with `blocks` workgroups of `threads` threads on
  * `stream` -- the launch shape of a collective's kernel (tools/collective_beside_probe.py). */
 int gkmhip_probe_copy(void *dst, const void *src, size_t bytes, int blocks, int threads, void *stream);

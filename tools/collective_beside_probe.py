@@ -154,6 +154,32 @@ def main():
             got.append((e0.elapsed_time(e1), ga.elapsed_time(e1), g0.elapsed_time(g1)))
         got = np.array(got[1:])
         print("%-22s %16.2f %22.2f %14.2f" % ("%d us" % pause, np.median(got[:, 0]), np.median(got[:, 1]), np.median(got[:, 2])), flush=True)
+
+    # ---- what a RESIDENT collective costs the kernel: workgroups that hold their wave slots and wait (for their peers, in
+    # the real thing; for the clock here) from just before the kernel starts until `hold` ms later
+    lib.gkmhip_probe_spin.restype = ctypes.c_int
+    lib.gkmhip_probe_spin.argtypes = (ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+    print("\nthe rank's Gram kernel (alone %.2f ms) beside workgroups that were on the device first and wait:" % gram_alone)
+    print("%-34s %12s %14s" % ("waiting workgroups", "held for ms", "kernel ms"))
+    for blocks, threads, hold in ((0, 0, 0), (32, 256, 6), (64, 256, 6), (64, 512, 6), (128, 512, 6)):
+        got = []
+        for _ in range(args.reps + 1):
+            g0, g1 = ev(), ev()
+            if blocks:
+                lib.gkmhip_probe_spin(blocks, threads, hold * 1000, side_handle)
+                t0 = time.perf_counter()
+                while time.perf_counter() - t0 < 2e-4:      # the waiting workgroups are resident before the kernel comes
+                    pass
+            ctx.kernel_timeline(True)
+            g0.record(main_stream)
+            gram()
+            g1.record(main_stream)
+            torch.cuda.synchronize(dev)
+            ms, k = ctx.kernel_timeline_ms()
+            ctx.kernel_timeline(False)
+            got.append(ms / k)
+        print("%-34s %12s %14.2f" % ("none" if not blocks else "%d x %d threads" % (blocks, threads), hold or "-", float(np.median(got[1:]))),
+              flush=True)
     ctx.close()
 
 
