@@ -363,15 +363,18 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
     HIPCHK(hipMemsetAsync(ctx->wd.p, weighted ? 0 : 1, WD_LDS, stream));
     if (weighted) HIPCHK(hipMemcpyAsync(ctx->wd.p, wdist, (size_t)wdist_len, hipMemcpyHostToDevice, stream));
     ctx->wd_len = weighted ? wdist_len : (ctx->maxlen - L + 1) / 2 + 1;
+    std::vector<uint8_t> wdc; /* (source of an asynchronous copy: alive until the wait at the end of this function) */
     {
         /* the centred copy: byte centre + s = wd[|s|] for |s| < wd_len, 0 outside; 4 bytes of slack below and 12 above
          * (k_gram_bitslice reads five consecutive bytes as an aligned pair of words) */
         const int B = ctx->wd_len - 1, centre = B + 4, bytes = ((centre + B + 1 + 12 + 3) / 4) * 4;
-        std::vector<uint8_t> wdc((size_t)bytes, 0);
+        wdc.assign((size_t)bytes, 0);
         for (int sd = -B; sd <= B; sd++) wdc[(size_t)(centre + sd)] = weighted ? wdist[sd < 0 ? -sd : sd] : (uint8_t)1;
-        if (ctx->wdc.ensure((size_t)bytes / 4)) return 4;
+        if (ctx->wdc.ensure((size_t)bytes / 4)) {
+            (void)hipStreamSynchronize(stream); /* (copies from the caller's arrays are in flight) */
+            return 4;
+        }
         HIPCHK(hipMemcpyAsync(ctx->wdc.p, wdc.data(), (size_t)bytes, hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream)); /* (the source is a local vector) */
         ctx->wdc_words = bytes / 4;
         ctx->wdc_centre = centre;
     }
@@ -380,15 +383,20 @@ extern "C" int gkmhip_set_sequences(gkmhip_ctx *ctx, int n, const uint8_t *codes
      * table built by the first launch on one stream was read by the second launch on the other stream before it was
      * complete (found when the host stopped waiting for its uploads: the config-4 stand-in through two contexts differed
      * in a few hundred rows). */
-    if (bitslice_serves(ctx) && (ensure_sb(ctx, 10, stream) || ensure_colpk(ctx, stream) || ensure_postab(ctx, stream))) return 4;
-    if (!bitslice_serves(ctx) && ensure_lmers(ctx, stream)) return 4;
-    /* the sources are the caller's (pageable) arrays: an asynchronous copy of more than a few KB may still be
-     * reading them after this call has returned, so the upload is finished here (3 MB, once per matrix) */
-    HIPCHK(hipStreamSynchronize(stream));
+    int rc = 0;
+    if (bitslice_serves(ctx)) rc = ensure_sb(ctx, 10, stream, false) || ensure_colpk(ctx, stream, false) || ensure_postab(ctx, stream, false);
+    else rc = ensure_lmers(ctx, stream, false);
+    /* ONE wait for everything enqueued above (round 5: five before).  The sources of the copies are the caller's (pageable)
+     * arrays and a local vector: an asynchronous copy of more than a few KB may still be reading them after this call has
+     * returned, so the upload is finished here, error or not (3 MB, once per matrix); and the tables are complete before a
+     * launch on any other stream reads them. */
+    const hipError_t done = hipStreamSynchronize(stream);
+    if (rc) return 4;
+    HIPCHK(done);
     return 0;
 }
 
-int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
+int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream, bool wait)
 {
     if (ctx->have_lmers) return 0;
     const size_t total_lm = (size_t)ctx->h_lmoff[(size_t)ctx->n];
@@ -400,12 +408,12 @@ int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream)
     hipLaunchKernelGGL(k_pack_lmers, dim3((unsigned)ctx->n), dim3(128), 0, stream, ctx->codes.p, ctx->off.p,
                        ctx->lmoff.p, ctx->L, ctx->wd.p, ctx->weighted, ctx->lmf.p, ctx->lmf.p + total_lm);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    if (wait) HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_lmers = true;
     return 0;
 }
 
-int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
+int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream, bool wait)
 {
     if (ctx->have_colpk) return 0;
     /* one word more than the bases need: the hit path reads words q/16 and q/16 + 1 */
@@ -415,12 +423,12 @@ int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream)
                        ctx->colpk.p);
     HIPCHK(hipGetLastError());
     ctx->pkw = pkw;
-    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    if (wait) HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_colpk = true;
     return 0;
 }
 
-int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream)
+int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream, bool wait)
 {
     if (ctx->have_postab) return 0;
     /* (+ 8: the same-length variant reads the bytes as aligned pairs of words around index .. index + 4) */
@@ -430,12 +438,12 @@ int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream)
                        ctx->postab.p);
     HIPCHK(hipGetLastError());
     ctx->ptw = ptw;
-    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    if (wait) HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_postab = true;
     return 0;
 }
 
-int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
+int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream, bool wait)
 {
     if (ctx->have_sb && ctx->sb_W == W) return 0;
     const int xw = ((ctx->maxlen + W + 2 * BS_DU + 15) / 16) * 16;
@@ -445,7 +453,7 @@ int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream)
     HIPCHK(hipGetLastError());
     ctx->sb_xw = xw;
     ctx->sb_W = W;
-    HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
+    if (wait) HIPCHK(hipStreamSynchronize(stream)); /* complete before any OTHER stream may read the table */
     ctx->have_sb = true;
     return 0;
 }

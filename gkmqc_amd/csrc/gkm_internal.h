@@ -146,10 +146,12 @@ int gkm_launch_events(gkmhip_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1);
 constexpr int WD_LDS = 1024; /* distance weight table entries: >= max |n/2 - p| + 1 for n <= 2047 */
 
 /* per-sequence device tables (gkm_context.hip): built by gkmhip_set_sequences, complete before any launch */
-int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream);
-int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream);
-int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream);
-int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream);
+/* (wait: the table is complete on return, so that a launch on ANOTHER stream may read it -- what a launch that finds the
+ * table missing needs; gkmhip_set_sequences builds all of them and waits once) */
+int ensure_lmers(gkmhip_ctx *ctx, hipStream_t stream, bool wait = true);
+int ensure_colpk(gkmhip_ctx *ctx, hipStream_t stream, bool wait = true);
+int ensure_postab(gkmhip_ctx *ctx, hipStream_t stream, bool wait = true);
+int ensure_sb(gkmhip_ctx *ctx, int W, hipStream_t stream, bool wait = true);
 bool bitslice_serves(const gkmhip_ctx *ctx); /* which kernel this context's launches take (gkm_gram.hip) */
 
 /* ------------------------------------------------------------ what a Gram launch writes */
