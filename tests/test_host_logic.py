@@ -96,6 +96,42 @@ def test_fasta_reader_edge_cases(dev, tmp_path):
         dev.read_problem(str(tmp_path / "missing.fa"), str(n))
 
 
+def test_fasta_reader_on_large_quirky_files(dev, tmp_path):
+    """The mmap reader against the oracle's on files of 0.4-0.7 MB (the quirks fixture is 20 KB) full of what can go wrong:
+    junk before the first header, CRLF, blank lines, multi-line records, '>' inside a line, records of 0 and of 3 000
+    bases (truncated at 2 047), lower case and N, a last line without its newline.  (Round 5 also parsed such files in
+    four ranges cut at headers, at the same time: same result, 0.3 ms of a 72-ms call -- not kept.)"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    letters = np.frombuffer(b"ACGTacgtNn", dtype=np.uint8)
+
+    def make(path, records, junk):
+        out = [junk]
+        for i in range(records):
+            kind = int(rng.integers(0, 10))
+            n = 0 if kind == 0 else 3000 if kind == 1 else int(rng.integers(1, 700))
+            seq = letters[rng.integers(0, 8 if kind < 8 else 10, n)].tobytes()
+            eol = b"\r\n" if kind == 2 else b"\n"
+            out.append(b">r%d with > inside the header" % i + eol)
+            width = int(rng.choice([60, 61, 80, 1000000]))
+            for at in range(0, len(seq), width):
+                line = seq[at:at + width]
+                out.append(line + (b" >not a header" if kind == 3 and at == 0 else b"") + eol)
+                if kind == 4:
+                    out.append(eol)
+        blob = b"".join(out)
+        path.write_bytes(blob[:-1])     # (the last line has no newline)
+        return len(blob)
+
+    p, n = tmp_path / "p.fa", tmp_path / "n.fa"
+    assert make(p, 2500, b"junk line\nmore junk > here\n") > 600 * 1024 and make(n, 1800, b"") > 400 * 1024
+    seqs, n_pos, n_invalid, n_trunc = dev.read_problem(str(p), str(n))
+    oseqs, o_pos, o_invalid, o_trunc = O.read_problem(str(p), str(n))
+    assert (n_pos, len(seqs)) == (o_pos, len(oseqs)) == (2500, 4300)
+    assert all(len(a) == len(b) and (a == b).all() for a, b in zip(seqs, oseqs))
+    assert (n_invalid, n_trunc) == (o_invalid, o_trunc) and n_trunc > 100 and n_invalid > 1000
+
+
 def _call_wrapper(dev, opt, nrows=64):
     kmat = np.full((nrows, nrows), -7.0)
     rows = (kmat.ctypes.data + np.arange(nrows) * kmat.strides[0]).astype(np.uintp)

@@ -50,6 +50,30 @@ int main(int argc, char **argv)
         r = walk(argv[2], "/tmp/gkm_asan_mut.fa");
         if (r < 0) rej++; else ok++;
     }
+    /* large files: the positive file repeated to ~700 KB, mutated the same way */
+    {
+        const long reps = 700 * 1024 / (len > 0 ? len : 1) + 1, bl = reps * len;
+        char *big = malloc((size_t)bl + 64);
+        for (long r = 0; r < reps; r++) memcpy(big + r * len, buf, (size_t)len);
+        long bok = 0, brej = 0;
+        for (int it = 0; it < 150; it++) {
+            char *m = malloc((size_t)bl + 64); memcpy(m, big, (size_t)bl); long ml = bl;
+            const int nm = 1 + (int)(rnd() % 64);
+            for (int k = 0; k < nm; k++) {
+                const int op = (int)(rnd() % 5); const long at = (long)(rnd() % (unsigned long)ml);
+                if (op == 0) m[at] = (char)(rnd() & 255);
+                else if (op == 1) m[at] = '>';
+                else if (op == 2) m[at] = '\n';
+                else if (op == 3 && it % 10 == 0) ml = at > 300 * 1024 ? at : ml;   /* truncate (keep it above the threshold) */
+                else if (op == 4) m[at] = '\r';
+            }
+            FILE *o = fopen("/tmp/gkm_asan_big.fa", "wb"); fwrite(m, 1, (size_t)ml, o); fclose(o); free(m);
+            if (walk("/tmp/gkm_asan_big.fa", argv[2]) < 0) brej++; else bok++;
+            if (walk(argv[2], "/tmp/gkm_asan_big.fa") < 0) brej++; else bok++;
+        }
+        printf("large files: %ld accepted, %ld rejected\n", bok, brej);
+        free(big);
+    }
     /* weights for every admissible parameter set */
     double c[13]; uint8_t wt[4096];
     for (int t = 0; t < 6; t++) for (int L = 2; L <= 12; L++) for (int k = 1; k <= L; k++) gkm_mismatch_weights(t, L, k, c);
